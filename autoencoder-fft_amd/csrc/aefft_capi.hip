@@ -1,0 +1,955 @@
+// C-ABI layer (include/aefft.h): context, workspaces, op-level entry points and the resident
+// batched network.  Host-side orchestration only -- all arithmetic lives in the *_kernels.hip files.
+#include "../../include/aefft.h"
+#include "internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace aefft;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+enum { WS_MID = 0, WS_REAL = 1, WS_G = 2, WS_HP = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_COUNT = 10 };
+
+// fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
+enum {
+    KID_R2C_ROWS = 0, KID_R2C_COLS, KID_C2R_COLS, KID_C2R_ROWS, KID_CONTRACT, KID_RESIZE, KID_DIFFMSE, KID_BIASGRAD,
+    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_COUNT
+};
+
+struct ProfEvent { hipEvent_t a, b; int kid; double bytes; };
+
+struct aefft_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    void* ws[WS_COUNT] = {};
+    size_t ws_bytes[WS_COUNT] = {};
+    bool prof = false;
+    std::vector<ProfEvent> pool;     // pre-created events
+    size_t used = 0;
+    long launches[KID_COUNT] = {};
+    double ms[KID_COUNT] = {};
+    double bytes[KID_COUNT] = {};
+};
+
+static int fail(aefft_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        ctx->err = buf;
+    }
+    return code;
+}
+#define HIPCHK(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) return fail(ctx, AEFFT_EHIP, #call, e_);        \
+    } while (0)
+#define RET_IF(x)                    \
+    do {                             \
+        int r_ = (x);                \
+        if (r_ != AEFFT_OK) return r_; \
+    } while (0)
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static int ws_get(aefft_ctx* ctx, int slot, size_t bytes, void** out)
+{
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
+        }
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) return fail(ctx, AEFFT_ENOMEM, "hipMalloc(workspace)", e);
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return AEFFT_OK;
+}
+
+// profiling brackets --------------------------------------------------------------------------
+struct Bracket {
+    aefft_ctx* ctx; int idx = -1;
+    Bracket(aefft_ctx* c, int kid, double bytes) : ctx(c)
+    {
+        if (!c->prof) return;
+        if (c->used >= c->pool.size()) return;   // pool exhausted: stop recording (read() reports what it has)
+        idx = (int)c->used++;
+        c->pool[idx].kid = kid; c->pool[idx].bytes = bytes;
+        (void)hipEventRecord(c->pool[idx].a, c->stream);
+    }
+    ~Bracket() { if (idx >= 0) (void)hipEventRecord(ctx->pool[idx].b, ctx->stream); }
+};
+
+extern "C" const char* aefft_version(void) { return "aefft 0.1 (gfx950)"; }
+
+extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream)
+{
+    if (!out) return AEFFT_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AEFFT_EHIP;
+    aefft_ctx* ctx = new aefft_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
+    if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
+        ctx->own_stream = true;
+    }
+    if (upload_twiddles(ctx->stream) != hipSuccess) { if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream); delete ctx; return AEFFT_EHIP; }
+    *out = ctx;
+    return AEFFT_OK;
+}
+
+extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < WS_COUNT; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* aefft_last_error(const aefft_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" int aefft_sync(aefft_ctx* ctx) { if (!ctx) return AEFFT_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return AEFFT_OK; }
+extern "C" void* aefft_stream(aefft_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int aefft_prof_enable(aefft_ctx* ctx, int enable)
+{
+    if (!ctx) return AEFFT_EINVAL;
+    if (enable && ctx->pool.empty()) {
+        ctx->pool.resize(8192);
+        for (auto& e : ctx->pool) { HIPCHK(ctx, hipEventCreate(&e.a)); HIPCHK(ctx, hipEventCreate(&e.b)); }
+    }
+    ctx->prof = enable != 0;
+    return AEFFT_OK;
+}
+
+static int prof_collect(aefft_ctx* ctx)
+{
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->used; ++i) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pool[i].a, ctx->pool[i].b));
+        const int k = ctx->pool[i].kid;
+        ctx->launches[k]++; ctx->ms[k] += ms; ctx->bytes[k] += ctx->pool[i].bytes;
+    }
+    ctx->used = 0;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_prof_reset(aefft_ctx* ctx)
+{
+    if (!ctx) return AEFFT_EINVAL;
+    RET_IF(prof_collect(ctx));
+    memset(ctx->launches, 0, sizeof ctx->launches); memset(ctx->ms, 0, sizeof ctx->ms); memset(ctx->bytes, 0, sizeof ctx->bytes);
+    return AEFFT_OK;
+}
+
+static const char* kid_names[KID_COUNT] = {"r2c_rows", "r2c_cols", "c2r_cols", "c2r_rows", "contract", "resize", "diff_mse",
+                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial"};
+
+extern "C" int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes)
+{
+    if (!ctx || kid < 0 || kid >= KID_COUNT) return AEFFT_EINVAL;
+    RET_IF(prof_collect(ctx));
+    if (launches) *launches = ctx->launches[kid];
+    if (total_ms) *total_ms = ctx->ms[kid];
+    if (algo_bytes) *algo_bytes = ctx->bytes[kid];
+    return AEFFT_OK;
+}
+extern "C" const char* aefft_prof_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kid_names[kid] : nullptr; }
+extern "C" int aefft_prof_count(void) { return KID_COUNT; }
+
+// ------------------------------------------------------------------------------------------
+// internal op helpers (all enqueue on ctx->stream)
+// ------------------------------------------------------------------------------------------
+static long bins(int Nx, int Ny) { return (long)Nx * (Ny / 2 + 1); }
+
+static int chk_size(aefft_ctx* ctx, int Nx, int Ny)
+{
+    if (!fft_size_supported(Nx) || !fft_size_supported(Ny)) return fail(ctx, AEFFT_EINVAL, "Nx, Ny must be powers of two in 8..2048");
+    return AEFFT_OK;
+}
+
+// R2C (+ fused crop to Nxs x Nys).  The two kernels are bracketed separately for profiling.
+static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys)
+{
+    RET_IF(chk_size(ctx, Nx, Ny));
+    if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
+    void* mid;
+    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * fft_mid_elems(planes, Nx, Nys / 2), &mid));
+    // launch_r2c issues rows then cols; bracket as two launches by splitting the byte accounting:
+    // rows: read planes*Nx*Ny*4, write mid; cols: read mid, write out.
+    const double b_in = (double)planes * Nx * Ny * 4, b_mid = (double)planes * Nx * (Nys / 2) * 8, b_out = (double)planes * bins(Nxs, Nys) * 8;
+    hipError_t e;
+    {
+        // The row and column kernels are launched inside launch_r2c; to time them separately we call it in two halves.
+        Bracket br(ctx, KID_R2C_ROWS, b_in + b_mid);
+        e = launch_r2c(x, nullptr, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c rows", e);
+    {
+        Bracket br(ctx, KID_R2C_COLS, b_mid + b_out);
+        e = launch_r2c(nullptr, X, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c cols", e);
+    return AEFFT_OK;
+}
+
+static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale)
+{
+    RET_IF(chk_size(ctx, Nx, Ny));
+    if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
+    void* mid;
+    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * fft_mid_elems(planes, Nx, Nyi / 2), &mid));
+    const double b_in = (double)planes * bins(Nxi, Nyi) * 8, b_mid = (double)planes * Nx * (Nyi / 2) * 8, b_out = (double)planes * Nx * Ny * 4;
+    hipError_t e;
+    {
+        Bracket br(ctx, KID_C2R_COLS, b_in + b_mid);
+        e = launch_c2r(X, nullptr, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r cols", e);
+    {
+        Bracket br(ctx, KID_C2R_ROWS, b_mid + b_out);
+        e = launch_c2r(nullptr, x, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r rows", e);
+    return AEFFT_OK;
+}
+
+static int do_contract(aefft_ctx* ctx, const Contract& q)
+{
+    // algorithmic bytes: A (R*K planes) + B (K*C planes) + Out (R*C planes), 8 B per bin
+    const double bytes = ((double)q.R * q.K + (double)q.K * q.C + (double)q.R * q.C) * q.P * 8.0;
+    Bracket br(ctx, KID_CONTRACT, bytes);
+    hipError_t e = launch_contract(q, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract", e);
+    return AEFFT_OK;
+}
+
+// conv_k over a batch: O[b][r] = sum_k (X[b][k]/R) * W[r][k] (+ bias[r]*Nx*Ny at DC)
+static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny)
+{
+    const long P = bins(Nx, Ny);
+    Contract q{};
+    q.A = W; q.a_r = (long)K * P; q.a_k = P;
+    q.B = X; q.b_k = P; q.b_c = (long)K * P;
+    q.Out = O; q.o_r = P; q.o_c = (long)R * P;
+    q.R = R; q.C = B; q.K = K; q.P = P;
+    q.conjA = q.conjB = false;
+    q.preDivB = (float)R;                       // in_t /= dM   (fft_backproplib.cu:176-177)
+    q.postDiv = 0.f;
+    q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
+    return do_contract(ctx, q);
+}
+
+static int do_resize(aefft_ctx* ctx, const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys)
+{
+    Bracket br(ctx, KID_RESIZE, (double)planes * (std::min(bins(Nx, Ny), bins(Nxs, Nys)) + bins(Nxs, Nys)) * 8.0);
+    hipError_t e = launch_resize(in, out, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "resize", e);
+    return AEFFT_OK;
+}
+
+static void pooled(int Nx, int Ny, int scale, int* Nxs, int* Nys)
+{
+    // fft_backproplib.cu:980-984 with power-of-two scales (exact in float)
+    if (scale > 0) { *Nxs = Nx / scale; *Nys = Ny / scale; }
+    else { *Nxs = Nx * (-scale); *Nys = Ny * (-scale); }
+}
+
+// E = O - T (optional) and mse (optional), mean over B:  scale = 1/(2*dM*Nx*Ny*B)
+static int do_diff_mse(aefft_ctx* ctx, const float2* T, const float2* O, float2* E, float* mse, int B, int dM, int dD, int Nx, int Ny)
+{
+    if (mse) HIPCHK(ctx, hipMemsetAsync(mse, 0, sizeof(float), ctx->stream));
+    const float scale = 1.0f / ((float)(2 * dM) * (float)Nx * (float)Ny * (float)B);
+    Bracket br(ctx, KID_DIFFMSE, (double)B * dD * bins(Nx, Ny) * 8.0 * (E ? 3 : 2));
+    hipError_t e = launch_diff_mse(T, O, E, mse, B, dD, Nx, Ny, scale, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "diff_mse", e);
+    return AEFFT_OK;
+}
+
+// gradient_k_io over a batch, given E = O - Xout.  G, Hp: workspaces [B][dM][P].
+static int do_gradient(aefft_ctx* ctx, const float2* Xin, const float2* E, const float2* C, const float2* F, const float* b,
+                       float2* G, float2* Hp, float2* dc, float2* df, float* db, float* dp, int B, int dM, int dD, int Nx, int Ny)
+{
+    const long P = bins(Nx, Ny);
+    const float norm = (float)Nx * (float)Ny;                 // fft_backproplib.cu:398
+    const float Norm = norm * 2 * dM * dD * Nx * Ny;          // :399 (float arithmetic, left to right)
+    {   // G[b][m] = sum_d1 conj(F[d1][m]) * E[b][d1]
+        Contract q{};
+        q.A = F; q.a_r = P; q.a_k = (long)dM * P; q.conjA = true;
+        q.B = E; q.b_k = P; q.b_c = (long)dD * P;
+        q.Out = G; q.o_r = P; q.o_c = (long)dM * P;
+        q.R = dM; q.C = B; q.K = dD; q.P = P;
+        RET_IF(do_contract(ctx, q));
+    }
+    {   // H'[b][m] = sum_d1 C[m][d1] * X[b][d1]  + b[m]*norm at DC (added after the sum, :454)
+        Contract q{};
+        q.A = C; q.a_r = (long)dD * P; q.a_k = P;
+        q.B = Xin; q.b_k = P; q.b_c = (long)dD * P;
+        q.Out = Hp; q.o_r = P; q.o_c = (long)dM * P;
+        q.R = dM; q.C = B; q.K = dD; q.P = P;
+        q.bias = b; q.biasScale = norm; q.biasAfterFirst = false;
+        RET_IF(do_contract(ctx, q));
+    }
+    {   // dc[m][d] = sum_b G[b][m] * conj(X[b][d]) / Norm   (mean over frames: / B)
+        Contract q{};
+        q.A = G; q.a_r = P; q.a_k = (long)dM * P;
+        q.B = Xin; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
+        q.Out = dc; q.o_r = (long)dD * P; q.o_c = P;
+        q.R = dM; q.C = dD; q.K = B; q.P = P;
+        q.postDiv = Norm * (float)B;
+        RET_IF(do_contract(ctx, q));
+    }
+    {   // df[d][m] = sum_b E[b][d] * conj(H'[b][m]) / Norm
+        Contract q{};
+        q.A = E; q.a_r = P; q.a_k = (long)dD * P;
+        q.B = Hp; q.b_k = (long)dM * P; q.b_c = P; q.conjB = true;
+        q.Out = df; q.o_r = (long)dM * P; q.o_c = P;
+        q.R = dD; q.C = dM; q.K = B; q.P = P;
+        q.postDiv = Norm * (float)B;
+        RET_IF(do_contract(ctx, q));
+    }
+    {
+        Bracket br(ctx, KID_BIASGRAD, (double)B * (dM + dD) * 8.0);
+        hipError_t e = launch_bias_grad(G, E, db, dp, B, dM, dD, P, norm, Norm, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "bias_grad", e);
+    }
+    return AEFFT_OK;
+}
+
+// unnormalised C2R of a gradient spectrum + shrink to the kernel support: g[planes][Nk][Nl]
+static int do_c2r_shrink(aefft_ctx* ctx, const float2* dspec, float* gk, float* realws, long planes, int Nx, int Ny, int Nk, int Nl)
+{
+    RET_IF(do_c2r(ctx, dspec, realws, planes, Nx, Ny, Nx, Ny, 1.0f));
+    Bracket br(ctx, KID_SHRINK, (double)planes * Nk * Nl * 8.0);
+    hipError_t e = launch_shrink(realws, gk, planes, Nx, Ny, Nk, Nl, 1.0f, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "shrink", e);
+    return AEFFT_OK;
+}
+
+// pad + R2C: kernel [planes][Nk][Nl] -> spectrum [planes][Nx][Nyr]
+static int do_pad_r2c(aefft_ctx* ctx, const float* k, float2* K, float* realws, long planes, int Nx, int Ny, int Nk, int Nl)
+{
+    {
+        Bracket br(ctx, KID_PAD, (double)planes * ((double)Nx * Ny + Nk * Nl) * 4.0);
+        hipError_t e = launch_pad(k, realws, planes, Nx, Ny, Nk, Nl, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "pad", e);
+    }
+    return do_r2c(ctx, realws, K, planes, Nx, Ny, Nx, Ny);
+}
+
+struct Momentum { float *Dc, *Df, *Db, *Dp; };
+
+// the coordinate-space part of `backprop` (fft_backproplib.cu:1229-1272) on already shrunk gradients
+static int do_update(aefft_ctx* ctx, float* c, float* f, float* b, float* p, const float* dck, const float* dfk, const float* db,
+                     const float* dp, Momentum mo, int dM, int dD, int Nk, int Nl, float del, int maxdiff, int sym, float gscale)
+{
+    UpdateArgs a{};
+    a.c = c; a.f = f; a.b = b; a.p = p;
+    a.dck = dck; a.dfk = dfk; a.db = db; a.dp = dp;
+    a.Dc = mo.Dc; a.Df = mo.Df; a.Db = mo.Db; a.Dp = mo.Dp;
+    a.dM = dM; a.dD = dD; a.Nk = Nk; a.Nl = Nl;
+    a.del = del; a.alpha = 0.9f; a.w0 = 1.f; a.w1 = 10.f;      // fft_backproplib.cu:608,1252
+    a.gscale = sym ? 0.5f * gscale : gscale; a.sym = sym;
+    if (maxdiff) {
+        const size_t nk = (size_t)dM * dD * Nk * Nl;
+        void *small, *den;
+        RET_IF(ws_get(ctx, WS_SMALL, sizeof(float) * (2 * nk + dM + dD + 64), &small));
+        RET_IF(ws_get(ctx, WS_DEN, sizeof(float) * 2 * (size_t)dM * dD * dM * dD, &den));
+        float* cd = (float*)small; float* fd = cd + nk; float* bd = fd + nk; float* pd = bd + dM;
+        {
+            Bracket br(ctx, KID_GDIFF, (double)nk * 16.0);
+            hipError_t e = launch_gradient_diff(c, f, b, p, cd, fd, bd, pd, (float*)den, dM, dD, Nk, Nl, ctx->stream);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "gradient_diff", e);
+        }
+        a.cd = cd; a.fd = fd; a.bd = bd; a.pd = pd;
+    }
+    Bracket br(ctx, KID_UPDATE, (double)dM * dD * Nk * Nl * 4.0 * 8);
+    hipError_t e = launch_update(a, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update", e);
+    return AEFFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// op-level C entry points
+// ------------------------------------------------------------------------------------------
+#define CF2(p) reinterpret_cast<const float2*>(p)
+#define F2(p) reinterpret_cast<float2*>(p)
+
+extern "C" int aefft_r2c(aefft_ctx* ctx, const float* x_d, float* X_d, long planes, int Nx, int Ny)
+{
+    if (!ctx || !x_d || !X_d || planes < 0) return fail(ctx, AEFFT_EINVAL, "aefft_r2c: bad argument");
+    return do_r2c(ctx, x_d, F2(X_d), planes, Nx, Ny, Nx, Ny);
+}
+
+extern "C" int aefft_c2r(aefft_ctx* ctx, const float* X_d, float* x_d, long planes, int Nx, int Ny, float scale)
+{
+    if (!ctx || !x_d || !X_d || planes < 0) return fail(ctx, AEFFT_EINVAL, "aefft_c2r: bad argument");
+    return do_c2r(ctx, CF2(X_d), x_d, planes, Nx, Ny, Nx, Ny, scale);
+}
+
+static int chk_scale(aefft_ctx* ctx, int Nx, int Ny, int scale, int* Nxs, int* Nys)
+{
+    const int a = scale < 0 ? -scale : scale;
+    if (scale == 0 || !pow2(a)) return fail(ctx, AEFFT_EINVAL, "pooling scale must be a non-zero power of two (SURVEY B-4)");
+    pooled(Nx, Ny, scale, Nxs, Nys);
+    if (*Nxs < 8 || *Nys < 8 || *Nxs > 2048 || *Nys > 2048) return fail(ctx, AEFFT_EINVAL, "pooled size out of range 8..2048");
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_pool(aefft_ctx* ctx, const float* X_d, float* Xs_d, long planes, int Nx, int Ny, int scale, int* Nxs, int* Nys)
+{
+    if (!ctx || !X_d || !Xs_d || planes < 0) return fail(ctx, AEFFT_EINVAL, "aefft_pool: bad argument");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    int nx, ny;
+    RET_IF(chk_scale(ctx, Nx, Ny, scale, &nx, &ny));
+    if (Nxs) *Nxs = nx;
+    if (Nys) *Nys = ny;
+    if (scale == 1 || scale == -1) {   // fft_backproplib.cu:977: nothing happens
+        HIPCHK(ctx, hipMemcpyAsync(Xs_d, X_d, sizeof(float2) * planes * bins(Nx, Ny), hipMemcpyDeviceToDevice, ctx->stream));
+        return AEFFT_OK;
+    }
+    return do_resize(ctx, CF2(X_d), F2(Xs_d), planes, Nx, Ny, nx, ny);
+}
+
+extern "C" int aefft_r2c_pool(aefft_ctx* ctx, const float* x_d, float* Xs_d, long planes, int Nx, int Ny, int scale)
+{
+    if (!ctx || !x_d || !Xs_d || planes < 0 || scale < 1) return fail(ctx, AEFFT_EINVAL, "aefft_r2c_pool: bad argument");
+    int nx, ny;
+    RET_IF(chk_scale(ctx, Nx, Ny, scale, &nx, &ny));
+    return do_r2c(ctx, x_d, F2(Xs_d), planes, Nx, Ny, nx, ny);
+}
+
+extern "C" int aefft_unpool_c2r(aefft_ctx* ctx, const float* Xs_d, float* x_d, long planes, int Nxs, int Nys, int scale, float out_scale)
+{
+    if (!ctx || !x_d || !Xs_d || planes < 0 || scale > -1) return fail(ctx, AEFFT_EINVAL, "aefft_unpool_c2r: scale must be <= -1");
+    int nx, ny;
+    RET_IF(chk_scale(ctx, Nxs, Nys, scale, &nx, &ny));
+    return do_c2r(ctx, CF2(Xs_d), x_d, planes, Nxs, Nys, nx, ny, out_scale);
+}
+
+extern "C" int aefft_kernel_spectrum(aefft_ctx* ctx, const float* k_d, float* K_d, int nA, int nB, int Nk, int Nl, int Nx, int Ny)
+{
+    if (!ctx || !k_d || !K_d || nA <= 0 || nB <= 0 || Nk <= 0 || Nl <= 0 || Nk > Nx || Nl > Ny) return fail(ctx, AEFFT_EINVAL, "aefft_kernel_spectrum: bad argument");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    const long planes = (long)nA * nB;
+    void* real;
+    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    return do_pad_r2c(ctx, k_d, F2(K_d), (float*)real, planes, Nx, Ny, Nk, Nl);
+}
+
+extern "C" int aefft_kernel_export(aefft_ctx* ctx, const float* K_d, float* k_d, int nA, int nB, int Nk, int Nl, int Nx, int Ny)
+{
+    if (!ctx || !k_d || !K_d || nA <= 0 || nB <= 0 || Nk <= 0 || Nl <= 0 || Nk > Nx || Nl > Ny) return fail(ctx, AEFFT_EINVAL, "aefft_kernel_export: bad argument");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    const long planes = (long)nA * nB;
+    void* real;
+    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    // kfft_inv: C2R then * 1/(Nx*Ny) (fft_backproplib.cu:948), then kernel_invpad
+    RET_IF(do_c2r(ctx, CF2(K_d), (float*)real, planes, Nx, Ny, Nx, Ny, 1.0f / ((float)Nx * (float)Ny)));
+    Bracket br(ctx, KID_SHRINK, (double)planes * Nk * Nl * 8.0);
+    hipError_t e = launch_shrink((const float*)real, k_d, planes, Nx, Ny, Nk, Nl, 1.0f, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "shrink", e);
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_conv(aefft_ctx* ctx, const float* X_d, const float* C_d, const float* bias_d, float* O_d, int B, int dM, int dD, int Nx, int Ny)
+{
+    if (!ctx || !X_d || !C_d || !O_d || B <= 0 || dM <= 0 || dD <= 0) return fail(ctx, AEFFT_EINVAL, "aefft_conv: bad argument");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    if (!aligned16(X_d) || !aligned16(C_d) || !aligned16(O_d)) return fail(ctx, AEFFT_EINVAL, "aefft_conv: pointers must be 16-byte aligned");
+    return do_conv(ctx, CF2(X_d), CF2(C_d), bias_d, F2(O_d), B, dM, dD, Nx, Ny);
+}
+
+extern "C" int aefft_gradient(aefft_ctx* ctx, const float* Xin_d, const float* Xout_d, const float* O_d, const float* C_d,
+                              const float* F_d, const float* b_d, float* dc_d, float* df_d, float* db_d, float* dp_d,
+                              int B, int dM, int dD, int Nx, int Ny)
+{
+    if (!ctx || !Xin_d || !Xout_d || !O_d || !C_d || !F_d || !b_d || !dc_d || !df_d || !db_d || !dp_d || B <= 0 || dM <= 0 || dD <= 0)
+        return fail(ctx, AEFFT_EINVAL, "aefft_gradient: bad argument");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    const long P = bins(Nx, Ny);
+    void *G, *Hp, *E;
+    RET_IF(ws_get(ctx, WS_G, sizeof(float2) * B * dM * P, &G));
+    RET_IF(ws_get(ctx, WS_HP, sizeof(float2) * B * dM * P, &Hp));
+    RET_IF(ws_get(ctx, WS_E, sizeof(float2) * B * dD * P, &E));
+    RET_IF(do_diff_mse(ctx, CF2(Xout_d), CF2(O_d), (float2*)E, nullptr, B, dM, dD, Nx, Ny));
+    return do_gradient(ctx, CF2(Xin_d), (float2*)E, CF2(C_d), CF2(F_d), b_d, (float2*)G, (float2*)Hp, F2(dc_d), F2(df_d), db_d, dp_d, B, dM, dD, Nx, Ny);
+}
+
+extern "C" int aefft_mse(aefft_ctx* ctx, const float* T_d, const float* O_d, float* mse_d, int B, int dM, int dD, int Nx, int Ny)
+{
+    if (!ctx || !T_d || !O_d || !mse_d || B <= 0) return fail(ctx, AEFFT_EINVAL, "aefft_mse: bad argument");
+    return do_diff_mse(ctx, CF2(T_d), CF2(O_d), nullptr, mse_d, B, dM, dD, Nx, Ny);
+}
+
+extern "C" int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, float* p_d, float* C_d, float* F_d,
+                            const float* dc_d, const float* df_d, const float* db_d, const float* dp_d,
+                            float* Dc_d, float* Df_d, float* Db_d, float* Dp_d,
+                            int dM, int dD, int Nx, int Ny, int Nk, int Nl, float del, int maxdiff)
+{
+    if (!ctx || !c_d || !f_d || !b_d || !p_d || !C_d || !F_d || !dc_d || !df_d || !db_d || !dp_d || !Dc_d || !Df_d || !Db_d || !Dp_d)
+        return fail(ctx, AEFFT_EINVAL, "aefft_update: null pointer");
+    RET_IF(chk_size(ctx, Nx, Ny));
+    const long planes = (long)dM * dD;
+    const size_t nk = (size_t)planes * Nk * Nl;
+    void *real, *tmp;
+    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * 2 * nk, &tmp));
+    float* dck = (float*)tmp; float* dfk = dck + nk;
+    RET_IF(do_c2r_shrink(ctx, CF2(dc_d), dck, (float*)real, planes, Nx, Ny, Nk, Nl));
+    RET_IF(do_c2r_shrink(ctx, CF2(df_d), dfk, (float*)real, planes, Nx, Ny, Nk, Nl));
+    RET_IF(do_update(ctx, c_d, f_d, b_d, p_d, dck, dfk, db_d, dp_d, Momentum{Dc_d, Df_d, Db_d, Dp_d}, dM, dD, Nk, Nl, del, maxdiff, 0, 1.0f));
+    RET_IF(do_pad_r2c(ctx, c_d, F2(C_d), (float*)real, planes, Nx, Ny, Nk, Nl));
+    RET_IF(do_pad_r2c(ctx, f_d, F2(F_d), (float*)real, planes, Nx, Ny, Nk, Nl));
+    return AEFFT_OK;
+}
+
+// spatial mode ------------------------------------------------------------------------------
+static void spatial_geom(int Nk, int Nl, int cpu_semantics, int* ak, int* al, int* lo)
+{
+    if (cpu_semantics) { *ak = (Nk - 1) / 2 - 1; *al = (Nl - 1) / 2 - 1; *lo = 1; }          // netlib.cpp:325-326,344
+    else { *ak = ((Nk - 1) / 2 - 1) / 2; *al = ((Nl - 1) / 2 - 1) / 2; *lo = 0; }             // backproplib.cu:123-124,95
+}
+
+extern "C" int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, const float* c_d, const float* b_d,
+                                  int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl, int cpu_semantics)
+{
+    if (!ctx || !in_d || !out_d || !c_d || !b_d || B <= 0 || dD <= 0 || dM <= 0 || Nx <= 0 || Ny <= 0 || Nk <= 0 || Nl <= 0)
+        return fail(ctx, AEFFT_EINVAL, "aefft_conv_spatial: bad argument");
+    int ak, al, lo;
+    spatial_geom(Nk, Nl, cpu_semantics, &ak, &al, &lo);
+    Bracket br(ctx, KID_SPATIAL, ((double)B * (dD + dM) * Nx * Ny + (double)dM * dD * Nk * Nl) * 4.0);
+    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics ? 1.f : (float)dM, lo, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "conv_spatial", e);
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
+                                      float* c_d, float* b_d, float* f_d, float* p_d,
+                                      float* dc_d, float* db_d, float* df_d, float* dp_d,
+                                      float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                                      int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                                      float delmax, float alpha, int tied, int cpu_semantics)
+{
+    if (!ctx || !in_d || !out_d || !hin_d || !c_d || !b_d || !f_d || !p_d || !dc_d || !db_d || !df_d || !dp_d || B <= 0)
+        return fail(ctx, AEFFT_EINVAL, "aefft_backprop_spatial: bad argument");
+    const size_t nk = (size_t)dM * dD * Nk * Nl;
+    void *ws, *small;
+    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * (size_t)B * dM * Nx * Ny, &ws));
+    RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * (2 * nk + dM + dD), &small));
+    SpatialGradArgs a{};
+    a.in = in_d; a.out = out_d; a.hin = hin_d; a.f = f_d;
+    a.gc = (float*)small; a.gf = a.gc + nk; a.gb = a.gf + nk; a.gp = a.gb + dM;
+    a.ws = (float*)ws;
+    a.B = B; a.dD = dD; a.dM = dM; a.Nx = Nx; a.Ny = Ny; a.Nk = Nk; a.Nl = Nl;
+    spatial_geom(Nk, Nl, cpu_semantics, &a.ak, &a.al, &a.lo);
+    a.Norm = (float)(dD * dM * Nk * Nl * Nx * Ny);            // backproplib.cu:303
+    if (tied) a.Norm = (float)(2 * dD * dM * Nk * Nl * Nx * Ny);   // :533
+    a.tied = tied;
+    {
+        Bracket br(ctx, KID_SPATIAL, (double)B * (3.0 * dD + 2.0 * dM) * Nx * Ny * 4.0);
+        hipError_t e = launch_spatial_grad(a, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "spatial_grad", e);
+    }
+    UpdateArgs u{};
+    u.c = c_d; u.f = f_d; u.b = b_d; u.p = p_d;
+    u.dck = a.gc; u.dfk = a.gf; u.db = a.gb; u.dp = a.gp;
+    u.Dc = dc_d; u.Df = df_d; u.Db = db_d; u.Dp = dp_d;
+    u.dM = dM; u.dD = dD; u.Nk = Nk; u.Nl = Nl;
+    u.del = delmax; u.alpha = alpha; u.w0 = 1.f; u.w1 = 0.f; u.gscale = 1.f; u.sym = tied;
+    u.ddc = ddc_d; u.ddf = tied ? nullptr : ddf_d; u.ddb = ddb_d; u.ddp = ddp_d;   // adapt_rate records the gradient (backproplib.cu:33)
+    {
+        Bracket br(ctx, KID_UPDATE, (double)nk * 4.0 * 8);
+        hipError_t e = launch_update(u, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update", e);
+    }
+    return AEFFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// resident network
+// ------------------------------------------------------------------------------------------
+struct Pair {
+    int dD, dM, Nk, Nl, s;
+    int Nxin, Nyin;          // resolution before this pair's pooling
+    int Nx, Ny;              // working resolution (after pooling)
+    long P;
+    float *c, *f, *b, *p;
+    float *Dc, *Df, *Db, *Dp;
+    float2 *C, *F;
+    bool spectra_valid;
+    float2 *X, *H, *O, *U;   // [B][dD][P], [B][dM][P], [B][dD][P], [B][dD][Pin] (U == O when s == 1; X aliases prev H when s == 1)
+    size_t goff;             // offset (floats) of this pair's segment in the packed gradient buffer
+};
+
+struct aefft_net {
+    aefft_ctx* ctx;
+    int D, Nx, Ny, L, B;
+    std::vector<Pair> pr;
+    std::vector<void*> allocs;
+    float2* A0 = nullptr;      // R2C of the frames when pair 0 does not pool (then X_0 == A0)
+    float* grad = nullptr; size_t grad_n = 0;
+    float* mse_pre = nullptr;  // [L]
+    float* mse_dev = nullptr;  // scratch for bursts
+    size_t mse_cap = 0;
+    const float* last_frames = nullptr;
+    bool have_forward = false, have_grad = false;
+    // shared scratch sized for the largest pair
+    float2 *G, *Hp, *E, *dc, *df;
+    float* real;
+};
+
+static int net_alloc(aefft_net* n, void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) return fail(n->ctx, AEFFT_ENOMEM, "hipMalloc(net)", e);
+    n->allocs.push_back(*p);
+    return AEFFT_OK;
+}
+template <typename T> static int net_alloc_t(aefft_net* n, T** p, size_t count) { return net_alloc(n, reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+extern "C" void aefft_net_destroy(aefft_net* net)
+{
+    if (!net) return;
+    (void)hipStreamSynchronize(net->ctx->stream);
+    for (void* p : net->allocs) (void)hipFree(p);
+    delete net;
+}
+
+extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_net** out)
+{
+    if (!ctx || !d || !out || d->npairs <= 0 || d->batch <= 0 || d->D <= 0 || !d->maps || !d->Nk || !d->Nl || !d->scale)
+        return fail(ctx, AEFFT_EINVAL, "aefft_net_create: bad descriptor");
+    *out = nullptr;
+    RET_IF(chk_size(ctx, d->Nx, d->Ny));
+    aefft_net* n = new aefft_net();
+    n->ctx = ctx; n->D = d->D; n->Nx = d->Nx; n->Ny = d->Ny; n->L = d->npairs; n->B = d->batch;
+    n->pr.resize(n->L);
+    int dD = d->D, nx = d->Nx, ny = d->Ny;
+    size_t maxBMP = 0, maxBDP = 0, maxW = 0, maxReal = 0, goff = 0, maxMid = 0, maxDen = 0, maxSmall = 0;
+    int rc = AEFFT_OK;
+    for (int l = 0; l < n->L && rc == AEFFT_OK; ++l) {
+        Pair& q = n->pr[l];
+        q.dD = dD; q.dM = d->maps[l]; q.Nk = d->Nk[l]; q.Nl = d->Nl[l]; q.s = d->scale[l];
+        q.Nxin = nx; q.Nyin = ny;
+        if (q.dM <= 0 || q.Nk <= 0 || q.Nl <= 0 || q.s < 1 || !pow2(q.s)) { rc = fail(ctx, AEFFT_EINVAL, "aefft_net_create: bad pair parameters"); break; }
+        q.Nx = nx / q.s; q.Ny = ny / q.s;
+        if (q.Nx < 8 || q.Ny < 8 || q.Nk > q.Nx || q.Nl > q.Ny) { rc = fail(ctx, AEFFT_EINVAL, "aefft_net_create: pooled size < 8 or kernel larger than plane"); break; }
+        q.P = bins(q.Nx, q.Ny);
+        const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+        if (nk < (size_t)q.dM || nk < (size_t)q.dD) { rc = fail(ctx, AEFFT_EINVAL, "aefft_net_create: degenerate kernel"); break; }
+        q.goff = goff; goff += 2 * nk + q.dM + q.dD;
+        float** w[] = {&q.c, &q.f, &q.Dc, &q.Df};
+        for (auto pp : w) if ((rc = net_alloc_t(n, pp, nk)) != AEFFT_OK) break;
+        if (rc) break;
+        if ((rc = net_alloc_t(n, &q.b, q.dM)) || (rc = net_alloc_t(n, &q.Db, q.dM)) || (rc = net_alloc_t(n, &q.p, q.dD)) || (rc = net_alloc_t(n, &q.Dp, q.dD))) break;
+        const size_t W = (size_t)q.dM * q.dD * q.P;
+        if ((rc = net_alloc_t(n, &q.C, W)) || (rc = net_alloc_t(n, &q.F, W))) break;
+        q.spectra_valid = false;
+        const size_t BDP = (size_t)n->B * q.dD * q.P, BMP = (size_t)n->B * q.dM * q.P;
+        if (q.s == 1 && l > 0) q.X = n->pr[l - 1].H;
+        else if ((rc = net_alloc_t(n, &q.X, BDP))) break;
+        if ((rc = net_alloc_t(n, &q.H, BMP)) || (rc = net_alloc_t(n, &q.O, BDP))) break;
+        if (q.s == 1) q.U = q.O;
+        else if ((rc = net_alloc_t(n, &q.U, (size_t)n->B * q.dD * bins(nx, ny)))) break;
+        maxBMP = std::max(maxBMP, BMP); maxBDP = std::max(maxBDP, BDP); maxW = std::max(maxW, W);
+        maxReal = std::max(maxReal, (size_t)q.dM * q.dD * q.Nx * q.Ny);
+        maxMid = std::max(maxMid, (size_t)q.dM * q.dD * q.Nx * (q.Ny / 2));
+        maxDen = std::max(maxDen, 2 * (size_t)q.dM * q.dD * q.dM * q.dD);
+        maxSmall = std::max(maxSmall, 2 * nk + q.dM + q.dD + 64);
+        dD = q.dM; nx = q.Nx; ny = q.Ny;
+    }
+    if (rc == AEFFT_OK) {
+        maxMid = std::max(maxMid, (size_t)n->B * n->D * n->Nx * (n->Ny / 2));
+        void* dummy;
+        // size the context workspaces once so nothing reallocates inside a step
+        if ((rc = ws_get(ctx, WS_MID, sizeof(float2) * maxMid, &dummy)) == AEFFT_OK &&
+            (rc = ws_get(ctx, WS_DEN, sizeof(float) * maxDen, &dummy)) == AEFFT_OK &&
+            (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->G, maxBMP)) == AEFFT_OK && (rc = net_alloc_t(n, &n->Hp, maxBMP)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->E, maxBDP)) == AEFFT_OK && (rc = net_alloc_t(n, &n->dc, maxW)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->df, maxW)) == AEFFT_OK && (rc = net_alloc_t(n, &n->real, maxReal)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->grad, goff)) == AEFFT_OK && (rc = net_alloc_t(n, &n->mse_pre, (size_t)n->L)) == AEFFT_OK) {
+            n->grad_n = goff;
+            if (n->pr[0].s == 1) n->A0 = n->pr[0].X;
+        }
+    }
+    if (rc != AEFFT_OK) { aefft_net_destroy(n); return rc; }
+    hipError_t e = hipSuccess;
+    for (auto& q : n->pr) {
+        const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+        e = hipMemsetAsync(q.c, 0, nk * 4, ctx->stream); if (e) break;
+        e = hipMemsetAsync(q.f, 0, nk * 4, ctx->stream); if (e) break;
+        e = hipMemsetAsync(q.b, 0, q.dM * 4, ctx->stream); if (e) break;
+        e = hipMemsetAsync(q.p, 0, q.dD * 4, ctx->stream); if (e) break;
+    }
+    if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset weights", e); }
+    *out = n;
+    return aefft_net_reset_momentum(n);
+}
+
+extern "C" int aefft_net_reset_momentum(aefft_net* n)
+{
+    if (!n) return AEFFT_EINVAL;
+    aefft_ctx* ctx = n->ctx;
+    for (auto& q : n->pr) {
+        const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+        HIPCHK(ctx, hipMemsetAsync(q.Dc, 0, nk * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(q.Df, 0, nk * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(q.Db, 0, q.dM * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(q.Dp, 0, q.dD * 4, ctx->stream));
+    }
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_set_pair(aefft_net* n, int l, const float* c_h, const float* b_h, const float* f_h, const float* p_h)
+{
+    if (!n || l < 0 || l >= n->L || !c_h || !b_h || !f_h || !p_h) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_set_pair: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    Pair& q = n->pr[l];
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    HIPCHK(ctx, hipMemcpyAsync(q.c, c_h, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.f, f_h, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be pageable / reused by the caller
+    q.spectra_valid = false;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_get_pair(aefft_net* n, int l, float* c_h, float* b_h, float* f_h, float* p_h)
+{
+    if (!n || l < 0 || l >= n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_pair: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    Pair& q = n->pr[l];
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    if (c_h) HIPCHK(ctx, hipMemcpyAsync(c_h, q.c, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (f_h) HIPCHK(ctx, hipMemcpyAsync(f_h, q.f, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_h) HIPCHK(ctx, hipMemcpyAsync(b_h, q.b, q.dM * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (p_h) HIPCHK(ctx, hipMemcpyAsync(p_h, q.p, q.dD * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return AEFFT_OK;
+}
+
+static int ensure_spectra(aefft_net* n, Pair& q)
+{
+    if (q.spectra_valid) return AEFFT_OK;
+    const long planes = (long)q.dM * q.dD;
+    RET_IF(do_pad_r2c(n->ctx, q.c, q.C, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    RET_IF(do_pad_r2c(n->ctx, q.f, q.F, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    q.spectra_valid = true;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_pair_spectra(aefft_net* n, int l, float** C_d, float** F_d)
+{
+    if (!n || l < 0 || l >= n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_pair_spectra: bad argument");
+    RET_IF(ensure_spectra(n, n->pr[l]));
+    if (C_d) *C_d = reinterpret_cast<float*>(n->pr[l].C);
+    if (F_d) *F_d = reinterpret_cast<float*>(n->pr[l].F);
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_store_spectra(aefft_net* n, int l, float* C_h, float* F_h)
+{
+    if (!n || l < 0 || l >= n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_store_spectra: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    Pair& q = n->pr[l];
+    RET_IF(ensure_spectra(n, q));
+    const size_t W = (size_t)q.dM * q.dD * q.P * sizeof(float2);
+    if (C_h) HIPCHK(ctx, hipMemcpyAsync(C_h, q.C, W, hipMemcpyDeviceToHost, ctx->stream));
+    if (F_h) HIPCHK(ctx, hipMemcpyAsync(F_h, q.F, W, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return AEFFT_OK;
+}
+
+// load_cfreq semantics (fft_backproplib.cu:1131-1141): the cached SPECTRA are the source of truth;
+// the coordinate-space kernels are re-derived from them (export_cfreq, :1166) to stay consistent.
+extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, const float* b_h, const float* F_h, const float* p_h)
+{
+    if (!n || l < 0 || l >= n->L || !C_h || !b_h || !F_h || !p_h) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_load_spectra: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    Pair& q = n->pr[l];
+    const size_t W = (size_t)q.dM * q.dD * q.P * sizeof(float2);
+    HIPCHK(ctx, hipMemcpyAsync(q.C, C_h, W, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.F, F_h, W, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    q.spectra_valid = true;
+    RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.C), q.c, q.dM, q.dD, q.Nk, q.Nl, q.Nx, q.Ny));
+    RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.F), q.f, q.dD, q.dM, q.Nk, q.Nl, q.Nx, q.Ny));
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* recon_d)
+{
+    if (!n || !frames_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_forward: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    const int B = n->B, L = n->L;
+    for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
+    // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
+    RET_IF(do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
+    for (int l = 0; l < L; ++l) {
+        Pair& q = n->pr[l];
+        if (l > 0 && q.s != 1) RET_IF(do_resize(ctx, n->pr[l - 1].H, q.X, (long)B * q.dD, q.Nxin, q.Nyin, q.Nx, q.Ny));
+        RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny));
+    }
+    // decoder (:1356-1361): conv then zero-pad up-sampling
+    const float2* Y = n->pr[L - 1].H;
+    for (int l = L - 1; l >= 0; --l) {
+        Pair& q = n->pr[l];
+        RET_IF(do_conv(ctx, Y, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
+        if (l > 0) {
+            if (q.s != 1) RET_IF(do_resize(ctx, q.O, q.U, (long)B * q.dD, q.Nx, q.Ny, q.Nxin, q.Nyin));
+            Y = q.U;
+        }
+    }
+    if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
+        Pair& q = n->pr[0];
+        RET_IF(do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny)));
+    }
+    n->last_frames = frames_d;
+    n->have_forward = true; n->have_grad = false;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* ch, int* nx, int* ny)
+{
+    if (!n || layer < 0 || layer > 4 * n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_layer: bad layer index");
+    aefft_ctx* ctx = n->ctx;
+    const int L = n->L, B = n->B;
+    int c, x, y, xi, yi;            // channels, output size, stored spectrum size
+    const float2* S = nullptr;
+    if (layer == 0) { c = n->D; x = xi = n->Nx; y = yi = n->Ny; }
+    else if (layer <= 2 * L) {
+        const Pair& q = n->pr[(layer - 1) / 2];
+        x = xi = q.Nx; y = yi = q.Ny;
+        if (layer & 1) { c = q.dD; S = q.X; } else { c = q.dM; S = q.H; }
+    } else {
+        const int nn = (layer - 1) / 2;           // decoder conv index L..2L-1
+        const Pair& q = n->pr[2 * L - 1 - nn];
+        c = q.dD; S = q.O; xi = q.Nx; yi = q.Ny;
+        if (layer & 1) { x = q.Nx; y = q.Ny; } else { x = q.Nxin; y = q.Nyin; }   // odd: conv output; even: up-sampled
+    }
+    if (ch) *ch = c;
+    if (nx) *nx = x;
+    if (ny) *ny = y;
+    if (!out_d) return AEFFT_OK;
+    if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_get_layer: no forward pass yet");
+    if (layer == 0) {
+        HIPCHK(ctx, hipMemcpyAsync(out_d, n->last_frames, sizeof(float) * B * c * x * y, hipMemcpyDeviceToDevice, ctx->stream));
+        return AEFFT_OK;
+    }
+    return do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y));
+}
+
+// one loop-body iteration on pair q given X (=T) and the current O; writes new H, O
+static int pair_grad(aefft_net* n, Pair& q, float* mse_slot)
+{
+    aefft_ctx* ctx = n->ctx;
+    // E = O - T (T = the pair's own input, autoencoder.cpp:194) fused with the pre-update MSE
+    RET_IF(do_diff_mse(ctx, q.X, q.O, n->E, mse_slot, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    float* g = n->grad + q.goff;
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    RET_IF(do_gradient(ctx, q.X, n->E, q.C, q.F, q.b, n->G, n->Hp, n->dc, n->df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    const long planes = (long)q.dM * q.dD;
+    RET_IF(do_c2r_shrink(ctx, n->dc, g, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    RET_IF(do_c2r_shrink(ctx, n->df, g + nk, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    return AEFFT_OK;
+}
+
+static int pair_apply(aefft_net* n, Pair& q, float del, int maxdiff, int sym, float gscale, float* mse_slot)
+{
+    aefft_ctx* ctx = n->ctx;
+    float* g = n->grad + q.goff;
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    RET_IF(do_update(ctx, q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
+                     q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale));
+    const long planes = (long)q.dM * q.dD;
+    RET_IF(do_pad_r2c(ctx, q.c, q.C, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    RET_IF(do_pad_r2c(ctx, q.f, q.F, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    // re-forward of this pair alone (fft_backproplib.cu:1460-1461) and its MSE (:1463)
+    RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, n->B, q.dD, q.dM, q.Nx, q.Ny));
+    if (mse_slot) RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, mse_slot, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0, int maxdiff, int sym, float* mse_h)
+{
+    if (!n || l < 0 || l >= n->L || n_iter < 0) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_train_pair: bad argument");
+    aefft_ctx* ctx = n->ctx;
+    if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
+    Pair& q = n->pr[l];
+    if ((size_t)(n_iter + 1) > n->mse_cap) {
+        float* nm;
+        RET_IF(net_alloc_t(n, &nm, (size_t)n_iter + 1));
+        n->mse_dev = nm; n->mse_cap = (size_t)n_iter + 1;
+    }
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    // momentum lives only inside the burst (fft_backproplib.cu:1420-1423)
+    HIPCHK(ctx, hipMemsetAsync(q.Dc, 0, nk * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(q.Df, 0, nk * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(q.Db, 0, q.dM * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(q.Dp, 0, q.dD * 4, ctx->stream));
+    const float del = 0.1f * del0;                      // :1445
+    if (n_iter == 0) RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_dev, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    for (int it = 0; it < n_iter; ++it) {
+        // the pre-update MSE of iteration `it` is the reference's print of iteration it-1 (or the initial one, :1440)
+        RET_IF(pair_grad(n, q, n->mse_dev + it));
+        RET_IF(pair_apply(n, q, del, maxdiff, sym, 1.0f, it == n_iter - 1 ? n->mse_dev + n_iter : nullptr));
+    }
+    n->have_grad = false;
+    if (mse_h) {
+        HIPCHK(ctx, hipMemcpyAsync(mse_h, n->mse_dev, sizeof(float) * (n_iter + 1), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* recon_d)
+{
+    if (!n) return AEFFT_EINVAL;
+    RET_IF(aefft_net_forward(n, frames_d, recon_d));
+    for (int l = 0; l < n->L; ++l) RET_IF(pair_grad(n, n->pr[l], n->mse_pre + l));
+    n->have_grad = true;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloats)
+{
+    if (!n) return AEFFT_EINVAL;
+    if (buf_d) *buf_d = n->grad;
+    if (nfloats) *nfloats = n->grad_n;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int sym, float grad_scale, float* mse_d)
+{
+    if (!n) return AEFFT_EINVAL;
+    if (!n->have_grad) return fail(n->ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
+    const float del = 0.1f * del0;
+    for (int l = 0; l < n->L; ++l) RET_IF(pair_apply(n, n->pr[l], del, maxdiff, sym, grad_scale, mse_d ? mse_d + l : nullptr));
+    n->have_grad = false;
+    return AEFFT_OK;
+}

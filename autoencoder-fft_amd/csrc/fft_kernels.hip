@@ -1,0 +1,496 @@
+// Batched 2-D real<->complex FFT for gfx950, written from scratch (no rocFFT/hipFFT).
+//
+// Replaces the reference's cuFFT call sites (fft_backproplib.cu:779-796 R2C, 821-829 C2R,
+// 885-910 / 937-946 kernel transforms, 1208-1220 / 1281-1282 in the training loop) and, when
+// asked, fuses the spectral pooling index remap of fft_backproplib.cu:87-157 (`resize`) into the
+// transform so cropped bins are never computed/stored and zero-padded bins never read.
+//
+// Structure (power-of-two sizes 8..2048):
+//   R2C  = row pass   : two real rows are packed as one complex row (a + i*b), one N-point
+//                       Stockham FFT in LDS, Hermitian split into the two half-spectra; the
+//                       DC and Nyquist columns (both real-valued) are packed into ONE complex
+//                       column so the intermediate is exactly N/2 columns wide (power of two,
+//                       16-byte aligned rows).
+//          column pass: tiles of CW columns x Nx rows staged through LDS (transposing load),
+//                       Nx-point FFTs, column 0 unpacked into DC / Nyquist on the way out.
+//   C2R  = the mirror image (column pass first), with the self-conjugate columns Hermitian-
+//          symmetrised on load so that imaginary parts of self-conjugate bins are ignored
+//          (pocketfft / numpy.irfft2 semantics; cuFFT leaves this unspecified).
+//
+// One transform of length N is computed by N/8 threads holding 8 complex values each:
+// radix-8 Stockham (decimation in frequency, auto-sort) passes with a final radix-4/2 pass,
+// data exchanged through LDS between passes (padded index n + n/8 against bank conflicts).
+#include "internal.h"
+#include <math.h>
+#include <vector>
+
+namespace aefft {
+
+__device__ float2 g_tw[TW_N];
+
+hipError_t upload_twiddles(hipStream_t st)
+{
+    static std::vector<float2> host;
+    if (host.empty()) {
+        host.resize(TW_N);
+        for (int k = 0; k < TW_N; ++k) {
+            double a = -2.0 * M_PI * (double)k / (double)TW_N;
+            host[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+    }
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tw), host.data(), sizeof(float2) * TW_N, 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+
+bool fft_size_supported(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// multiply by exp(DIR*i*pi/2): -i for the forward transform, +i for the inverse
+template <int DIR> __device__ __forceinline__ float2 mul_i(float2 a)
+{
+    return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+template <int DIR> __device__ __forceinline__ float2 twid(int idx)
+{
+    float2 w = g_tw[idx];
+    if (DIR > 0) w.y = -w.y;
+    return w;
+}
+
+template <int R, int DIR> struct Dft;
+template <int DIR> struct Dft<2, DIR> {
+    static __device__ __forceinline__ void run(float2* a)
+    {
+        float2 t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    }
+};
+template <int DIR> struct Dft<4, DIR> {
+    static __device__ __forceinline__ void run(float2* a)
+    {
+        float2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+        float2 t2 = cadd(a[1], a[3]), t3 = mul_i<DIR>(csub(a[1], a[3]));
+        a[0] = cadd(t0, t2); a[1] = cadd(t1, t3); a[2] = csub(t0, t2); a[3] = csub(t1, t3);
+    }
+};
+template <int DIR> struct Dft<8, DIR> {
+    static __device__ __forceinline__ void run(float2* a)
+    {
+        float2 e[4] = {a[0], a[2], a[4], a[6]};
+        float2 o[4] = {a[1], a[3], a[5], a[7]};
+        Dft<4, DIR>::run(e);
+        Dft<4, DIR>::run(o);
+        const float c = 0.70710678118654752440f;
+        // o[u] *= w8^u, w8 = exp(DIR*i*pi/4)
+        float2 o1, o3;
+        if (DIR < 0) {
+            o1 = make_float2(c * (o[1].x + o[1].y), c * (o[1].y - o[1].x));
+            o3 = make_float2(c * (o[3].y - o[3].x), -c * (o[3].x + o[3].y));
+        } else {
+            o1 = make_float2(c * (o[1].x - o[1].y), c * (o[1].x + o[1].y));
+            o3 = make_float2(-c * (o[3].x + o[3].y), c * (o[3].x - o[3].y));
+        }
+        float2 o2 = mul_i<DIR>(o[2]);
+        a[0] = cadd(e[0], o[0]); a[4] = csub(e[0], o[0]);
+        a[1] = cadd(e[1], o1);   a[5] = csub(e[1], o1);
+        a[2] = cadd(e[2], o2);   a[6] = csub(e[2], o2);
+        a[3] = cadd(e[3], o3);   a[7] = csub(e[3], o3);
+    }
+};
+
+__host__ __device__ constexpr int pad_idx(int n) { return n + (n >> 3); }
+__host__ __device__ constexpr int pad_len(int n) { return n + (n >> 3) + 2; }
+
+// One Stockham pass of radix R at stride S (= product of earlier radices) on a transform of
+// length N held in LDS at `s` (padded indexing); `t` is this thread's index inside the
+// transform, 0..N/8-1.  Butterfly ib reads elements ib + tt*(N/R) and writes q + S*(R*p + u)
+// with p = ib / S, q = ib % S, twiddle W_n^(p*u), n = N/S.  In place: read, barrier, write, barrier.
+template <int N, int R, int S, int DIR>
+__device__ __forceinline__ void fft_pass(float2* s, int t)
+{
+    constexpr int T = N / 8;
+    constexpr int E = 8 / R;
+    constexpr int n = N / S;
+    float2 a[8];
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int ib = t + T * v;
+#pragma unroll
+        for (int tt = 0; tt < R; ++tt) a[v * R + tt] = s[pad_idx(ib + tt * (N / R))];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int ib = t + T * v;
+        const int p = ib / S, q = ib % S;
+        Dft<R, DIR>::run(&a[v * R]);
+        if (n > R) {
+            const int base = p * (TW_N / n);
+#pragma unroll
+            for (int u = 1; u < R; ++u) a[v * R + u] = cmul(a[v * R + u], twid<DIR>(u * base));
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) s[pad_idx(q + S * (R * p + u))] = a[v * R + u];
+    }
+    __syncthreads();
+}
+
+template <int N, int S, int DIR> struct Passes {
+    static __device__ __forceinline__ void run(float2* s, int t)
+    {
+        constexpr int n = N / S;
+        constexpr int R = n >= 8 ? 8 : n;
+        fft_pass<N, R, S, DIR>(s, t);
+        Passes<N, S * R, DIR>::run(s, t);
+    }
+};
+template <int N, int DIR> struct Passes<N, N, DIR> {
+    static __device__ __forceinline__ void run(float2*, int) {}
+};
+
+// Caller must have issued __syncthreads() after filling `s`; on return the result is in `s`
+// (natural order) and visible to the whole workgroup.
+template <int N, int DIR> __device__ __forceinline__ void fft_lds(float2* s, int t) { Passes<N, 1, DIR>::run(s, t); }
+
+// ------------------------------------------------------------------------------------------
+// row pass, forward: real rows -> packed half spectra
+// ------------------------------------------------------------------------------------------
+template <int N> struct RowCfg {
+    static constexpr int T = N / 8;
+    static constexpr int NT = T > 256 ? T : 256;
+    static constexpr int G = NT / T;          // row PAIRS per workgroup
+    static constexpr int PL = pad_len(N);
+};
+
+// Hermitian split of Z = FFT(a + i*b): element k of row `row` (0: a, 1: b) in the packed layout
+// (k = 0 carries DC in .x and Nyquist in .y).
+template <int N> __device__ __forceinline__ float2 split_rows(const float2* z, int k, int row)
+{
+    if (k == 0) {
+        float2 z0 = z[pad_idx(0)], zh = z[pad_idx(N / 2)];
+        return row == 0 ? make_float2(z0.x, zh.x) : make_float2(z0.y, zh.y);
+    }
+    float2 zk = z[pad_idx(k)], zn = z[pad_idx(N - k)];
+    return row == 0 ? make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y))
+                    : make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+}
+
+template <int N>
+__global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __restrict__ in, float2* __restrict__ mid,
+                                                                   long npairs, int Wc)
+{
+    using Cfg = RowCfg<N>;
+    constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
+    extern __shared__ float2 s[];
+    const int tid = threadIdx.x;
+    const int g = tid / T, t = tid % T;
+    const long pair0 = (long)blockIdx.x * G;
+
+    constexpr int NV = G * 2 * N / 4;
+    const float4* src = reinterpret_cast<const float4*>(in + pair0 * 2 * N);
+    for (int v = tid; v < NV; v += NT) {
+        const int e = v * 4;
+        const int gg = e / (2 * N), o = e % (2 * N);
+        const int row = o / N, n0 = o % N;
+        if (pair0 + gg < npairs) {
+            const float4 val = src[v];
+            float* dst = reinterpret_cast<float*>(s + gg * PL) + row;
+            dst[2 * pad_idx(n0)] = val.x;
+            dst[2 * pad_idx(n0 + 1)] = val.y;
+            dst[2 * pad_idx(n0 + 2)] = val.z;
+            dst[2 * pad_idx(n0 + 3)] = val.w;
+        }
+    }
+    __syncthreads();
+    fft_lds<N, -1>(s + g * PL, t);
+
+    const int half = Wc / 2;
+    for (int it = tid; it < G * 2 * half; it += NT) {
+        const int gg = it / (2 * half), rem = it % (2 * half);
+        const int row = rem / half, k = (rem % half) * 2;
+        if (pair0 + gg >= npairs) continue;
+        const float2* z = s + gg * PL;
+        const float2 r0 = split_rows<N>(z, k, row), r1 = split_rows<N>(z, k + 1, row);
+        float4* dst = reinterpret_cast<float4*>(mid + ((pair0 + gg) * 2 + row) * Wc + k);
+        *dst = make_float4(r0.x, r0.y, r1.x, r1.y);
+    }
+}
+
+// row pass, inverse: packed half spectra (Wc columns, the rest zero) -> two real rows
+template <int N>
+__global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* __restrict__ mid, float* __restrict__ out,
+                                                                   long npairs, int Wc, float scale)
+{
+    using Cfg = RowCfg<N>;
+    constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
+    extern __shared__ float2 s[];
+    const int tid = threadIdx.x;
+    const int g = tid / T, t = tid % T;
+    const long pair0 = (long)blockIdx.x * G;
+
+    // Z[k] = A[k] + i*B[k], Z[N-k] = conj(A[k]) + i*conj(B[k]); k handled in pairs (k, k+1), k even < N/2
+    for (int it = tid; it < G * (N / 4); it += NT) {
+        const int gg = it / (N / 4), k = (it % (N / 4)) * 2;
+        if (pair0 + gg >= npairs) continue;
+        float2* z = s + gg * PL;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (k < Wc) {
+            const float2* rowA = mid + ((pair0 + gg) * 2) * Wc;
+            a = *reinterpret_cast<const float4*>(rowA + k);
+            b = *reinterpret_cast<const float4*>(rowA + Wc + k);
+        }
+        if (k == 0) {
+            z[pad_idx(0)] = make_float2(a.x, b.x);          // DC of both rows (imaginary parts ignored)
+            z[pad_idx(N / 2)] = make_float2(a.y, b.y);      // Nyquist, carried in .y of the packed column
+        } else {
+            z[pad_idx(k)] = make_float2(a.x - b.y, a.y + b.x);
+            z[pad_idx(N - k)] = make_float2(a.x + b.y, -a.y + b.x);
+        }
+        z[pad_idx(k + 1)] = make_float2(a.z - b.w, a.w + b.z);
+        z[pad_idx(N - k - 1)] = make_float2(a.z + b.w, -a.w + b.z);
+    }
+    __syncthreads();
+    fft_lds<N, +1>(s + g * PL, t);
+
+    constexpr int NV = G * 2 * N / 4;
+    float4* dst = reinterpret_cast<float4*>(out + pair0 * 2 * N);
+    for (int v = tid; v < NV; v += NT) {
+        const int e = v * 4;
+        const int gg = e / (2 * N), o = e % (2 * N);
+        const int row = o / N, n0 = o % N;
+        if (pair0 + gg < npairs) {
+            const float* zs = reinterpret_cast<const float*>(s + gg * PL) + row;
+            dst[v] = make_float4(zs[2 * pad_idx(n0)] * scale, zs[2 * pad_idx(n0 + 1)] * scale,
+                                 zs[2 * pad_idx(n0 + 2)] * scale, zs[2 * pad_idx(n0 + 3)] * scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// column passes
+// ------------------------------------------------------------------------------------------
+// source row of destination row i when the spectrum is cropped from Nx to Nxs rows (fft.cu:102-104)
+__device__ __forceinline__ int crop_row(int i, int Nx, int Nxs)
+{
+    if (Nxs == Nx || i < Nxs / 2) return i;
+    if (i == Nxs / 2) return Nx / 2;
+    return i + Nx - Nxs;
+}
+// source row (of Nxi) feeding destination row r (of Nx) under zero-pad up-sampling (fft.cu:119-133); -1 = zero
+__device__ __forceinline__ int padsrc_row(int r, int Nx, int Nxi)
+{
+    if (Nx == Nxi) return r;
+    if (r < Nxi / 2) return r;
+    if (r > Nx - Nxi / 2) return r - Nx + Nxi;
+    if (r == Nx / 2) return Nxi / 2;
+    return -1;
+}
+
+// forward: mid [planes][N][Wc] -> out [planes][Nxs][Wc+1], FFT along x (length N)
+template <int N, int CW>
+__global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __restrict__ mid, float2* __restrict__ out,
+                                                              int Wc, int Nxs)
+{
+    constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
+    extern __shared__ float2 s[];
+    const int tid = threadIdx.x;
+    const long plane = blockIdx.x;
+    const int c0 = blockIdx.y * CW;
+
+    const float2* src = mid + plane * N * (long)Wc + c0;
+    for (int it = tid; it < N * (CW / 2); it += NT) {
+        const int r = it / (CW / 2), c2 = it % (CW / 2);
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)r * Wc + 2 * c2);
+        s[(2 * c2) * PL + pad_idx(r)] = make_float2(v.x, v.y);
+        s[(2 * c2 + 1) * PL + pad_idx(r)] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    fft_lds<N, -1>(s + (tid / T) * PL, tid % T);
+
+    const int Nyrs = Wc + 1;
+    float2* dst = out + plane * Nxs * (long)Nyrs;
+    for (int it = tid; it < Nxs * CW; it += NT) {
+        const int i = it / CW, c = it % CW;
+        const int si = crop_row(i, N, Nxs);
+        const float2 z = s[c * PL + pad_idx(si)];
+        const int col = c0 + c;
+        if (col == 0) {
+            // column 0 carries DC + i*Nyquist of the row pass: split by Hermitian symmetry along x
+            const float2 zn = s[pad_idx((N - si) % N)];
+            dst[(long)i * Nyrs] = make_float2(0.5f * (z.x + zn.x), 0.5f * (z.y - zn.y));
+            dst[(long)i * Nyrs + Wc] = make_float2(0.5f * (z.y + zn.y), -0.5f * (z.x - zn.x));
+        } else {
+            dst[(long)i * Nyrs + col] = z;
+        }
+    }
+}
+
+// inverse: in [planes][Nxi][Wc+1] (rows zero-padded to N) -> mid [planes][N][Wc], inverse FFT along x
+template <int N, int CW>
+__global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __restrict__ in, float2* __restrict__ mid,
+                                                              int Wc, int Nxi)
+{
+    constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
+    extern __shared__ float2 s[];
+    const int tid = threadIdx.x;
+    const long plane = blockIdx.x;
+    const int c0 = blockIdx.y * CW;
+    const int Nyri = Wc + 1;
+    const float2* src = in + plane * Nxi * (long)Nyri;
+
+    for (int it = tid; it < N * CW; it += NT) {
+        const int r = it / CW, c = it % CW;
+        const int col = c0 + c;
+        const int sr = padsrc_row(r, N, Nxi);
+        float2 z = make_float2(0.f, 0.f);
+        if (col == 0) {
+            // Hermitian-symmetrise the two self-conjugate columns (imaginary parts of self-conjugate
+            // bins are thereby ignored) and pack them as DC + i*Nyquist
+            const int sm = padsrc_row((N - r) % N, N, Nxi);
+            float2 d0 = z, d1 = z, n0 = z, n1 = z;
+            if (sr >= 0) { d0 = src[(long)sr * Nyri]; n0 = src[(long)sr * Nyri + Wc]; }
+            if (sm >= 0) { d1 = src[(long)sm * Nyri]; n1 = src[(long)sm * Nyri + Wc]; }
+            const float2 dc = make_float2(0.5f * (d0.x + d1.x), 0.5f * (d0.y - d1.y));
+            const float2 ny = make_float2(0.5f * (n0.x + n1.x), 0.5f * (n0.y - n1.y));
+            z = make_float2(dc.x - ny.y, dc.y + ny.x);
+        } else if (sr >= 0) {
+            z = src[(long)sr * Nyri + col];
+        }
+        s[c * PL + pad_idx(r)] = z;
+    }
+    __syncthreads();
+    fft_lds<N, +1>(s + (tid / T) * PL, tid % T);
+
+    float2* dst = mid + plane * N * (long)Wc + c0;
+    for (int it = tid; it < N * (CW / 2); it += NT) {
+        const int r = it / (CW / 2), c2 = it % (CW / 2);
+        const float2 a = s[(2 * c2) * PL + pad_idx(r)], b = s[(2 * c2 + 1) * PL + pad_idx(r)];
+        *reinterpret_cast<float4*>(dst + (long)r * Wc + 2 * c2) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+size_t fft_mid_elems(long planes, int Nx, int Wc) { return (size_t)planes * Nx * Wc; }
+
+template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, long npairs, int Wc, hipStream_t st)
+{
+    using Cfg = RowCfg<N>;
+    const size_t lds = sizeof(float2) * Cfg::G * Cfg::PL;
+    hipError_t e = allow_lds(r2c_rows_kernel<N>, lds);
+    if (e != hipSuccess) return e;
+    const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
+    r2c_rows_kernel<N><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(in, mid, npairs, Wc);
+    return hipGetLastError();
+}
+template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, long npairs, int Wc, float scale, hipStream_t st)
+{
+    using Cfg = RowCfg<N>;
+    const size_t lds = sizeof(float2) * Cfg::G * Cfg::PL;
+    hipError_t e = allow_lds(c2r_rows_kernel<N>, lds);
+    if (e != hipSuccess) return e;
+    const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
+    c2r_rows_kernel<N><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(mid, out, npairs, Wc, scale);
+    return hipGetLastError();
+}
+template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st)
+{
+    const size_t lds = sizeof(float2) * CW * pad_len(N);
+    hipError_t e = allow_lds(fwd_cols_kernel<N, CW>, lds);
+    if (e != hipSuccess) return e;
+    fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
+    return hipGetLastError();
+}
+template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2* mid, long planes, int Wc, int Nxi, hipStream_t st)
+{
+    const size_t lds = sizeof(float2) * CW * pad_len(N);
+    hipError_t e = allow_lds(inv_cols_kernel<N, CW>, lds);
+    if (e != hipSuccess) return e;
+    inv_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(in, mid, Wc, Nxi);
+    return hipGetLastError();
+}
+
+// column tile width: at most 16, at most Wc, and CW*N/8 <= 1024 threads
+template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, float2* b, long planes, int Wc, int Nother, hipStream_t st)
+{
+    constexpr int CWMAX = (8192 / N) < 16 ? (8192 / N) : 16;
+    int cw = CWMAX;
+    while (cw > Wc) cw >>= 1;
+#define AEFFT_CW_CASE(C)                                                                                   \
+    if constexpr (C <= CWMAX) {                                                                             \
+        if (cw == C) return FWD ? run_fwd_cols<N, C>(a, b, planes, Wc, Nother, st) : run_inv_cols<N, C>(a, b, planes, Wc, Nother, st); \
+    }
+    AEFFT_CW_CASE(16) AEFFT_CW_CASE(8) AEFFT_CW_CASE(4)
+#undef AEFFT_CW_CASE
+    return hipErrorInvalidValue;
+}
+
+#define AEFFT_N_SWITCH(n, CALL)                       \
+    switch (n) {                                      \
+    case 8: { constexpr int NN = 8; CALL; }           \
+    case 16: { constexpr int NN = 16; CALL; }         \
+    case 32: { constexpr int NN = 32; CALL; }         \
+    case 64: { constexpr int NN = 64; CALL; }         \
+    case 128: { constexpr int NN = 128; CALL; }       \
+    case 256: { constexpr int NN = 256; CALL; }       \
+    case 512: { constexpr int NN = 512; CALL; }       \
+    case 1024: { constexpr int NN = 1024; CALL; }     \
+    case 2048: { constexpr int NN = 2048; CALL; }     \
+    default: e = hipErrorInvalidValue;                \
+    }
+
+// `in` non-null: run the row pass (in -> mid); `out` non-null: run the column pass (mid -> out).
+hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st)
+{
+    if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxs > Nx || Nys > Ny || Nys < 8 || Nxs < 2 || (Nys & 1) || (Nxs & 1))
+        return hipErrorInvalidValue;
+    if (planes <= 0) return hipSuccess;
+    const int Wc = Nys / 2;
+    const long npairs = planes * Nx / 2;
+    hipError_t e = hipSuccess;
+    if (in) {
+        AEFFT_N_SWITCH(Ny, e = run_r2c_rows<NN>(in, mid, npairs, Wc, st); break)
+        if (e != hipSuccess) return e;
+    }
+    if (out) {
+        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, true>(mid, out, planes, Wc, Nxs, st)); break)
+    }
+    return e;
+}
+
+// `in` non-null: run the column pass (in -> mid); `out` non-null: run the row pass (mid -> out).
+hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, hipStream_t st)
+{
+    if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxi > Nx || Nyi > Ny || Nyi < 8 || Nxi < 2 || (Nyi & 1) || (Nxi & 1))
+        return hipErrorInvalidValue;
+    if ((Nxi == Nx) != (Nyi == Ny)) return hipErrorInvalidValue;   // pad both axes or none
+    if (planes <= 0) return hipSuccess;
+    const int Wc = Nyi / 2;
+    const long npairs = planes * Nx / 2;
+    hipError_t e = hipSuccess;
+    if (in) {
+        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, false>(in, mid, planes, Wc, Nxi, st)); break)
+        if (e != hipSuccess) return e;
+    }
+    if (out) {
+        AEFFT_N_SWITCH(Ny, e = run_c2r_rows<NN>(mid, out, npairs, Wc, scale, st); break)
+    }
+    return e;
+}
+
+}  // namespace aefft

@@ -1,0 +1,85 @@
+// Internal launch interface between the HIP kernel files and the C-ABI layer (aefft_capi.hip).
+// Nothing here is exported; the public boundary is include/aefft.h and the three C++ headers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace aefft {
+
+// ---- fft_kernels.hip -------------------------------------------------------------------
+// Twiddle table W[k] = exp(-2*pi*i*k/TW_N), uploaded once per device.
+constexpr int TW_N = 4096;
+hipError_t upload_twiddles(hipStream_t st);
+bool fft_size_supported(int n);
+
+// Batched 2-D R2C with optional fused spectral crop (== fft.cu:764 `fft` followed by
+// fft.cu:87 `resize` down-sampling to Nxs x Nys).  in [planes][Nx][Ny] real ->
+// out [planes][Nxs][Nys/2+1] complex.  `mid` is a workspace of planes*Nx*(Nys/2) complex.
+hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny,
+                      int Nxs, int Nys, hipStream_t st);
+// Batched 2-D C2R with optional fused spectral zero-pad (== `resize` up-sampling from
+// Nxi x Nyi, then cufftExecC2R, then * scale).  in [planes][Nxi][Nyi/2+1] -> out [planes][Nx][Ny].
+hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi,
+                      int Nx, int Ny, float scale, hipStream_t st);
+size_t fft_mid_elems(long planes, int Nx, int Wc);   // complex elements needed in `mid`
+
+// ---- spectral_kernels.hip --------------------------------------------------------------
+// Per-bin complex contraction  Out[r][c][bin] = alpha * sum_k opA(A[r][k][bin]) * opB(B[k][c][bin])
+// (+ bias[r]*biasScale added to Re at bin 0), the one primitive behind conv_k (fft.cu:162) and
+// both halves of gradient_k_io (fft.cu:395).  Strides are in complex elements.
+struct Contract {
+    const float2* A; long a_r, a_k;     // A[r][k] plane base = A + r*a_r + k*a_k
+    const float2* B; long b_k, b_c;     // B[k][c] plane base = B + k*b_k + c*b_c
+    float2* Out;     long o_r, o_c;     // Out[r][c] plane base
+    int R, C, K;                        // rows, cols, contraction length
+    long P;                             // bins per plane
+    bool conjA, conjB;
+    float preDivB;                      // !=0: B elements are divided by this BEFORE the product (conv_k: in/dM, fft.cu:176-177)
+    float postDiv;                      // !=0: the sum is divided by this (gradient_k_io: /Norm, fft.cu:440-441)
+    const float* bias; float biasScale; // Re(Out[r][c][0]) += bias[r]*biasScale; null = none
+    bool biasAfterFirst;                // true: added right after the k==0 term (fft.cu:183-184); false: after the sum (fft.cu:454)
+};
+hipError_t launch_contract(const Contract& q, hipStream_t st);
+
+hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st);
+// E = O - T and MSE (fft.cu:480-498): *mse_acc += scale * sum_bins |T-O|^2/n_bin.
+hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullable*/, float* mse_acc /*1 float, pre-zeroed, nullable*/,
+                           int B, int ch, int Nx, int Ny, float scale, hipStream_t st);
+// db[m] = mean_b Re G_b[m](0) * norm/Norm ; dp[d] = mean_b Re E_b[d](0) * norm/Norm  (fft.cu:463-473)
+hipError_t launch_bias_grad(const float2* G, const float2* E, float* db, float* dp, int B, int dM, int dD, long P,
+                            float norm, float Norm, hipStream_t st);
+
+// ---- update_kernels.hip ----------------------------------------------------------------
+hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);   // fft.cu:570 (zero-fills)
+hipError_t launch_shrink(const float* cpad, float* ck, long planes, int Nx, int Ny, int Nk, int Nl, float scale, hipStream_t st); // fft.cu:535
+struct UpdateArgs {
+    float *c, *f, *b, *p;                 // weights, updated in place
+    const float *dck, *dfk, *db, *dp;     // gradients (coordinate space)
+    float *Dc, *Df, *Db, *Dp;             // momentum
+    const float *cd, *fd, *bd, *pd;       // multiobjective gradients (null when maxdiff=0)
+    int dM, dD, Nk, Nl;
+    float del, alpha, w0, w1;
+    float gscale;                         // gradients are multiplied by this first (1/world_size for data-parallel means)
+    int sym;                              // tied weights: g = g_c[m][d] + g_f[d][m], f[d][m] <- c[m][d]
+    float *ddc, *ddf, *ddb, *ddp;         // optional: record the gradients used (adapt_rate, backproplib.cu:33); may be null
+};
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st);                                      // fft.cu:605 / 657
+hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
+                                float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st);   // fft.cu:709
+
+// ---- spatial_kernels.hip ---------------------------------------------------------------
+hipError_t launch_conv_spatial(const float* in, float* out, const float* c, const float* b, int B, int dD, int dM,
+                               int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st);
+struct SpatialGradArgs {
+    const float *in, *out, *hin, *f;      // [dD][Nx][Ny], [dD][Nx][Ny], [dM][Nx][Ny], [dD][dM][Nk][Nl]
+    float *gc, *gf, *gb, *gp;             // [dM][dD][Nk][Nl], [dD][dM][Nk][Nl], [dM], [dD]
+    float *ws;                            // workspace: dM*Nx*Ny (back-conv) floats
+    int B, dD, dM, Nx, Ny, Nk, Nl, ak, al;
+    float Norm;
+    int lo;                               // 0: GPU boundary test '>=0' (backproplib.cu:95), 1: CPU test '>0' (netlib.cpp:344)
+    int tied;                             // backprop_gpu_cc: add the f-gradient into the c-gradient (backproplib.cu:466)
+};
+hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st);
+
+}  // namespace aefft

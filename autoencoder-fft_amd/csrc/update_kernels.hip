@@ -1,0 +1,194 @@
+// Coordinate-space side of the weight update for gfx950:
+//   pad / shrink of the centred-wrapped Nk x Nl kernel support  (fft_backproplib.cu:535-600)
+//   clipped-gradient + momentum update                          (fft_backproplib.cu:605-652, 657-704)
+//   kernel-distance gradient of the multiobjective mode         (fft_backproplib.cu:709-753)
+// These tensors are tiny (dM*dD*Nk*Nl floats); the kernels are launch-latency bound.
+#include "internal.h"
+
+namespace aefft {
+
+// tap k of Nk -> row of the padded plane: (k - Nk/2) mod Nx   (fft_backproplib.cu:544-563)
+__device__ __forceinline__ int tap_row(int k, int Nk, int Nx) { return k >= Nk / 2 ? k - Nk / 2 : k + Nx - Nk / 2; }
+// inverse: padded row i -> tap index, or -1
+__device__ __forceinline__ int row_tap(int i, int Nk, int Nx)
+{
+    if (i + Nk / 2 < Nk) return i + Nk / 2;
+    if (i >= Nx - Nk / 2) return i - (Nx - Nk / 2);
+    return -1;
+}
+
+// memset + pad_k in one pass: every element of the padded plane is written.
+__global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ ck, float* __restrict__ cpad, long planes,
+                                                  int Nx, int Ny, int Nk, int Nl)
+{
+    const long total = planes * Nx * (long)Ny;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pl = idx / ((long)Nx * Ny);
+        const int rem = (int)(idx - pl * (long)Nx * Ny);
+        const int i = rem / Ny, j = rem % Ny;
+        const int k = row_tap(i, Nk, Nx), l = row_tap(j, Nl, Ny);
+        cpad[idx] = (k >= 0 && l >= 0) ? ck[(pl * Nk + k) * Nl + l] : 0.f;
+    }
+}
+
+hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st)
+{
+    if (Nk > Nx || Nl > Ny) return hipErrorInvalidValue;
+    const long total = planes * Nx * (long)Ny;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    pad_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(ck, cpad, planes, Nx, Ny, Nk, Nl);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void shrink_kernel(const float* __restrict__ cpad, float* __restrict__ ck, long planes,
+                                                     int Nx, int Ny, int Nk, int Nl, float scale)
+{
+    const long total = planes * Nk * Nl;
+    const long idk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idk >= total) return;
+    const long pl = idk / (Nk * Nl);
+    const int rem = (int)(idk - pl * Nk * Nl);
+    const int k = rem / Nl, l = rem % Nl;
+    ck[idk] = cpad[(pl * Nx + tap_row(k, Nk, Nx)) * (long)Ny + tap_row(l, Nl, Ny)] * scale;
+}
+
+hipError_t launch_shrink(const float* cpad, float* ck, long planes, int Nx, int Ny, int Nk, int Nl, float scale, hipStream_t st)
+{
+    const long total = planes * Nk * Nl;
+    shrink_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(cpad, ck, planes, Nx, Ny, Nk, Nl, scale);
+    return hipGetLastError();
+}
+
+// D <- (1-alpha)*del*g/max(10,|g|) + alpha*D ; w <- w - D      (fft_backproplib.cu:616-618)
+__device__ __forceinline__ float clip_step(float g, float D, float del, float alpha)
+{
+    const float ag = fabsf(g);
+    return (1 - alpha) * del * g / ((10 < ag) ? ag : 10) + alpha * D;
+}
+
+__global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a)
+{
+    const int n = a.dM * a.dD * a.Nk * a.Nl;
+    const int idk = blockIdx.x * 256 + threadIdx.x;
+    if (idk >= n) return;
+    const bool multi = a.cd != nullptr;
+    if (!a.sym) {
+        float gc = a.dck[idk] * a.gscale, gf = a.dfk[idk] * a.gscale;
+        if (a.ddc) a.ddc[idk] = gc;
+        if (a.ddf) a.ddf[idk] = gf;
+        if (multi) { gc = a.w0 * gc - a.w1 * a.cd[idk]; gf = a.w0 * gf - a.w1 * a.fd[idk]; }
+        const float Dc = clip_step(gc, a.Dc[idk], a.del, a.alpha);
+        a.c[idk] += -Dc; a.Dc[idk] = Dc;
+        const float Df = clip_step(gf, a.Df[idk], a.del, a.alpha);
+        a.f[idk] += -Df; a.Df[idk] = Df;
+    } else {
+        // tied weights: g = g_c[m][d] + g_f[d][m] with the caller's doubled Norm (backproplib.cu:533,466);
+        // c <- c - D ; f[d][m] <- c[m][d] (:621-622).  FFT mode: build-defined.
+        const int kl = a.Nk * a.Nl;
+        const int m = idk / (a.dD * kl), d = (idk / kl) % a.dD, r = idk % kl;
+        const int idf = (d * a.dM + m) * kl + r;
+        float g = (a.dck[idk] + a.dfk[idf]) * a.gscale;
+        if (a.ddc) a.ddc[idk] = g;
+        if (multi) g = a.w0 * g - a.w1 * 0.5f * (a.cd[idk] + a.fd[idf]);
+        const float Dc = clip_step(g, a.Dc[idk], a.del, a.alpha);
+        const float cn = a.c[idk] - Dc;
+        a.c[idk] = cn; a.Dc[idk] = Dc;
+        a.f[idf] = cn;
+    }
+    if (idk < a.dM) {
+        float g = a.db[idk] * a.gscale;
+        if (a.ddb) a.ddb[idk] = g;
+        if (multi) g = a.w0 * g - a.w1 * a.bd[idk];
+        const float Db = clip_step(g, a.Db[idk], a.del, a.alpha);
+        a.b[idk] += -Db; a.Db[idk] = Db;
+    }
+    if (idk < a.dD) {
+        float g = a.dp[idk] * a.gscale;
+        if (a.ddp) a.ddp[idk] = g;
+        if (multi) g = a.w0 * g - a.w1 * a.pd[idk];
+        const float Dp = clip_step(g, a.Dp[idk], a.del, a.alpha);
+        a.p[idk] += -Dp; a.Dp[idk] = Dp;
+    }
+}
+
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
+{
+    const int n = a.dM * a.dD * a.Nk * a.Nl;
+    if (n < a.dM || n < a.dD) return hipErrorInvalidValue;   // the reference's idk<dM / idk<dD trick needs this too
+    update_kernel<<<dim3((n + 255) / 256), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient_diff (fft_backproplib.cu:709-753).  The reference recomputes the squared kernel
+// distance den(m,d;m1,d1) inside every (k,l) thread; here it is computed once per kernel pair
+// (same k1,l1 summation order, so identical floats) into `den_ws` = 2*(dM*dD)^2 floats, then
+// each (m,d,k,l) thread sums (w - w1)/den over the partners in the reference's (m1,d1) order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kdist_kernel(const float* __restrict__ c, const float* __restrict__ f,
+                                                    float* __restrict__ den, int dM, int dD, int kl)
+{
+    const long np = (long)dM * dD;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= np * np) return;
+    const int a = (int)(idx / np), b = (int)(idx % np);
+    const int m = a / dD, d = a % dD, m1 = b / dD, d1 = b % dD;
+    float dc = 0.f, df = 0.f;
+    const float* ca = c + (long)a * kl;
+    const float* cb = c + (long)b * kl;
+    const float* fa = f + ((long)d * dM + m) * kl;
+    const float* fb = f + ((long)d1 * dM + m1) * kl;
+    for (int t = 0; t < kl; ++t) {
+        const float x = ca[t] - cb[t], y = fa[t] - fb[t];
+        dc += x * x; df += y * y;
+    }
+    den[idx] = dc;
+    den[np * np + idx] = df;
+}
+
+__global__ __launch_bounds__(256) void gradient_diff_kernel(const float* __restrict__ c, const float* __restrict__ f,
+                                                            const float* __restrict__ b, const float* __restrict__ p,
+                                                            const float* __restrict__ den, float* __restrict__ cd,
+                                                            float* __restrict__ fd, float* __restrict__ bd,
+                                                            float* __restrict__ pd, int dM, int dD, int Nk, int Nl)
+{
+    const int kl = Nk * Nl;
+    const long np = (long)dM * dD;
+    const long idk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idk >= np * kl) return;
+    const int a = (int)(idk / kl), r = (int)(idk % kl);
+    const int m = a / dD, d = a % dD;
+    const float cw = c[idk], fw = f[((long)d * dM + m) * kl + r];
+    float sc = 0.f, sf = 0.f, sb = 0.f, sp = 0.f;
+    for (int m1 = 0; m1 < dM; ++m1) {
+        for (int d1 = 0; d1 < dD; ++d1) {
+            if (m1 != m && d1 != d) {
+                const long pb = (long)m1 * dD + d1;
+                sc += (cw - c[pb * kl + r]) / den[(long)a * np + pb];
+                sf += (fw - f[((long)d1 * dM + m1) * kl + r]) / den[np * np + (long)a * np + pb];
+            }
+            if (m1 == 0 && d1 != d) sp += 1.f / (p[d] - p[d1]);
+        }
+        if (m1 != m) sb += 1.f / (b[m] - b[m1]);
+    }
+    cd[idk] = sc;
+    fd[((long)d * dM + m) * kl + r] = sf;
+    // every thread of a given m (d) writes the same value; keep a single writer
+    if (d == 0 && r == 0) bd[m] = sb;
+    if (m == 0 && r == 0) pd[d] = sp;
+}
+
+hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
+                                float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st)
+{
+    const long np = (long)dM * dD;
+    const int kl = Nk * Nl;
+    kdist_kernel<<<dim3((unsigned)((np * np + 255) / 256)), 256, 0, st>>>(c, f, den_ws, dM, dD, kl);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    gradient_diff_kernel<<<dim3((unsigned)((np * kl + 255) / 256)), 256, 0, st>>>(c, f, b, p, den_ws, cd, fd, bd, pd, dM, dD, Nk, Nl);
+    return hipGetLastError();
+}
+
+}  // namespace aefft

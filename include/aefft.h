@@ -1,0 +1,188 @@
+/* aefft.h -- flat C ABI of the MI355X-native FFT-convolution autoencoder training path.
+ *
+ * This is the drop-in boundary UNDER the reference's C++ operator headers.  The reference
+ * (fabrii4/AutoEncoder-FFT) exposes its hot path as C++ free functions over nested std::vector
+ * (source/fft_backproplib.h:5-11, source/backproplib.h:5-16, source/netlib.h:4-24); those same
+ * functions are re-exported, mangled identically, by include/fft_backproplib.h, backproplib.h and
+ * netlib.h of this repo, and are thin marshalling shims over the entry points below.  Every entry
+ * point here names the reference function (file:line) whose arithmetic it reproduces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types.
+ *   - "_d" pointers are DEVICE pointers (16-byte aligned), "_h" are host pointers.
+ *   - real tensors  : float32, [ch][Nx][Ny]   (x = first index, y contiguous; reference layout)
+ *   - spectra       : interleaved complex64 (float pairs), [ch][Nx][Nyr], Nyr = Ny/2+1
+ *   - encoder kernel: c[dM][dD][Nk][Nl], bias b[dM]; decoder kernel f[dD][dM][Nk][Nl], bias p[dD]
+ *   - batches add an outermost [B] dimension.  B = 1 reproduces the reference call exactly.
+ *   - Nx, Ny: powers of two in 8..2048.  Pooling scales: powers of two.
+ *   - every function returns AEFFT_OK (0) or an error code; aefft_last_error() gives the text.
+ *     Work is enqueued on the context's stream; nothing blocks unless stated.
+ *   - there is NO CPU fallback: every call fails with AEFFT_EHIP when no MI355X is present.
+ */
+#ifndef AEFFT_H
+#define AEFFT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aefft_ctx aefft_ctx;   /* device + stream + twiddle tables + workspace pool */
+typedef struct aefft_net aefft_net;   /* a stacked autoencoder resident on the device       */
+
+enum {
+    AEFFT_OK = 0,
+    AEFFT_EINVAL = 1,       /* bad argument (size not a power of two, misaligned pointer, ...) */
+    AEFFT_EHIP = 2,         /* HIP runtime error / no device */
+    AEFFT_ENOMEM = 3,
+    AEFFT_ESTATE = 4        /* call order violated (e.g. train before forward) */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* `hip_stream`: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let the
+ * context create its own non-blocking stream. */
+int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream);
+void aefft_ctx_destroy(aefft_ctx* ctx);
+const char* aefft_last_error(const aefft_ctx* ctx);
+int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
+void* aefft_stream(aefft_ctx* ctx);             /* the hipStream_t in use */
+const char* aefft_version(void);
+
+/* ---- op level: one entry point per reference device routine --------------------------------- */
+
+/* fft_backproplib.cu:764-801 `fft`: batched unnormalised 2-D R2C.  x_d [planes][Nx][Ny] -> X_d [planes][Nx][Nyr]. */
+int aefft_r2c(aefft_ctx* ctx, const float* x_d, float* X_d, long planes, int Nx, int Ny);
+/* fft_backproplib.cu:806-864 `fft_inv` (scale = 1/(Nx*Ny)) and the bare cufftExecC2R of
+ * :1219-1220 (scale = 1).  Imaginary parts of self-conjugate bins are ignored. */
+int aefft_c2r(aefft_ctx* ctx, const float* X_d, float* x_d, long planes, int Nx, int Ny, float scale);
+/* fft_backproplib.cu:975-1002 `pool_fft` + :87-157 `resize`: scale > 1 crops to Nx/scale,
+ * scale < -1 zero-pads to Nx*|scale|, no amplitude rescale.  Out-of-place; *Nxs,*Nys receive
+ * the new size (may be NULL). */
+int aefft_pool(aefft_ctx* ctx, const float* X_d, float* Xs_d, long planes, int Nx, int Ny, int scale, int* Nxs, int* Nys);
+/* Fused forms used by the resident network (same arithmetic, fewer bytes):
+ * r2c followed by pool(scale>=1), and pool(scale<=-1) followed by c2r. */
+int aefft_r2c_pool(aefft_ctx* ctx, const float* x_d, float* Xs_d, long planes, int Nx, int Ny, int scale);
+int aefft_unpool_c2r(aefft_ctx* ctx, const float* Xs_d, float* x_d, long planes, int Nxs, int Nys, int scale, float out_scale);
+
+/* fft_backproplib.cu:1018-1064 `kernel_pad` + :869-916 `kfft` (first pass of StoreLoad_cfreq,
+ * :1146-1158): k_d [nA][nB][Nk][Nl] -> K_d [nA][nB][Nx][Nyr]. */
+int aefft_kernel_spectrum(aefft_ctx* ctx, const float* k_d, float* K_d, int nA, int nB, int Nk, int Nl, int Nx, int Ny);
+/* fft_backproplib.cu:1166-1172 `export_cfreq` (= `kfft_inv` :921-970 + `kernel_invpad` :1069-1112). */
+int aefft_kernel_export(aefft_ctx* ctx, const float* K_d, float* k_d, int nA, int nB, int Nk, int Nl, int Nx, int Ny);
+
+/* fft_backproplib.cu:1007-1013 `conv_fft` / :162-189 `conv_k`:
+ *   O[b][m] = sum_d (X[b][d]/dM) * C[m][d];  Re O[b][m](0,0) += bias[m]*Nx*Ny.
+ * X_d [B][dD][P], C_d [dM][dD][P], bias_d [dM], O_d [B][dM][P]. */
+int aefft_conv(aefft_ctx* ctx, const float* X_d, const float* C_d, const float* bias_d, float* O_d,
+               int B, int dM, int dD, int Nx, int Ny);
+
+/* fft_backproplib.cu:395-475 `gradient_k_io`.  Xin/Xout/O [B][dD][P]; C [dM][dD][P]; F [dD][dM][P];
+ * outputs dc [dM][dD][P], df [dD][dM][P], db [dM], dp [dD]; for B > 1 the mean over frames. */
+int aefft_gradient(aefft_ctx* ctx, const float* Xin_d, const float* Xout_d, const float* O_d, const float* C_d,
+                   const float* F_d, const float* b_d, float* dc_d, float* df_d, float* db_d, float* dp_d,
+                   int B, int dM, int dD, int Nx, int Ny);
+
+/* fft_backproplib.cu:1178-1192 `mse_fft` (+ :480-498 `calc_mse`); mean over the B frames.
+ * mse_d: one float on the device. */
+int aefft_mse(aefft_ctx* ctx, const float* T_d, const float* O_d, float* mse_d, int B, int dM, int dD, int Nx, int Ny);
+
+/* fft_backproplib.cu:1197-1291 host `backprop`: unnormalised C2R of dc/df, shrink_k (:535),
+ * backprop_d (:605) or gradient_diff + backprop_double (:709,:657) when maxdiff, pad_k (:570),
+ * R2C -> new C, F.  c,f,b,p and the momentum buffers Dc,Df,Db,Dp are updated in place.
+ * `del` is the step actually applied (the reference passes 0.1*del0, :1445). */
+int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, float* p_d, float* C_d, float* F_d,
+                 const float* dc_d, const float* df_d, const float* db_d, const float* dp_d,
+                 float* Dc_d, float* Df_d, float* Db_d, float* Dp_d,
+                 int dM, int dD, int Nx, int Ny, int Nk, int Nl, float del, int maxdiff);
+
+/* ---- spatial mode (coordinate space) --------------------------------------------------------- */
+/* backproplib.cu:114-182 `Conv_gpu` (+ :70-111 `conv_parallel`): zero-padded direct convolution,
+ * tap offset -2*ak-1+k with ak=((Nk-1)/2-1)/2, input divided by dM first (:134), + b[m].
+ * in_d [B][dD][Nx][Ny] -> out_d [B][dM][Nx][Ny].  cpu_semantics=1 gives netlib.cpp:318-358 `Conv`
+ * instead (ak=(Nk-1)/2-1, boundary test '>0', no division). */
+int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, const float* c_d, const float* b_d,
+                       int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl, int cpu_semantics);
+/* backproplib.cu:291-418 `backprop_gpu` (tied=0) / :521-644 `backprop_gpu_cc` (tied=1): back-conv
+ * through f + weight-gradient correlation, then the inertia update
+ *   d <- (1-alpha)*delmax*g/max(10,|g|) + alpha*d ; w <- w - d     (:392-396)
+ * dc..dp are the caller's persistent previous-update buffers, ddc..ddp receive the gradients
+ * (adapt_rate, :28-35, is otherwise inert -- Appendix B-12).  All device pointers; for B > 1 the
+ * gradient is the mean over frames.  Gradient index/stale-buffer bugs of gradient_CF (Appendix
+ * B-11) are NOT replicated: indices follow the CPU reference (netlib.cpp:425-430). */
+int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
+                           float* c_d, float* b_d, float* f_d, float* p_d,
+                           float* dc_d, float* db_d, float* df_d, float* dp_d,
+                           float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                           int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                           float delmax, float alpha, int tied, int cpu_semantics);
+
+/* ---- network level: the resident, batched form of autoenc_fft / backprop_fft ------------------ */
+typedef struct {
+    int D, Nx, Ny;        /* input frames [B][D][Nx][Ny] */
+    int npairs;           /* L encoder/decoder pairs (net_c holds 2L kernels, autoencoder.cpp:115-116,414-417) */
+    const int* maps;      /* [L] feature maps dM of each pair */
+    const int* Nk;        /* [L] kernel rows */
+    const int* Nl;        /* [L] kernel cols */
+    const int* scale;     /* [L] pooling scale s>=1 of each pair (decoder mirrors with -s, autoencoder.cpp:119-120) */
+    int batch;            /* frames per call on this GPU */
+} aefft_net_desc;
+
+int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* desc, aefft_net** out);
+void aefft_net_destroy(aefft_net* net);
+/* weights of pair l (host pointers, reference layouts).  set = the caller's net_cfreq.clear():
+ * spectra are rebuilt from c,f (fft_backproplib.cu:1148-1158). */
+int aefft_net_set_pair(aefft_net* net, int l, const float* c_h, const float* b_h, const float* f_h, const float* p_h);
+int aefft_net_get_pair(aefft_net* net, int l, float* c_h, float* b_h, float* f_h, float* p_h);
+/* device views of the cached kernel spectra (C [dM][dD][P], F [dD][dM][P]) of pair l */
+int aefft_net_pair_spectra(aefft_net* net, int l, float** C_d, float** F_d);
+/* the caller-side `net_cfreq` cache (fft_backproplib.cu:1117-1141 store_cfreq / load_cfreq): host
+ * copies of the spectra, interleaved floats in the reference layout.  load makes the spectra the
+ * source of truth and re-derives c, f from them (export_cfreq, :1166). */
+int aefft_net_store_spectra(aefft_net* net, int l, float* C_h, float* F_h);
+int aefft_net_load_spectra(aefft_net* net, int l, const float* C_h, const float* b_h, const float* F_h, const float* p_h);
+
+/* fft_backproplib.cu:1331-1376 `autoenc_fft` over a batch.  frames_d [B][D][Nx][Ny];
+ * recon_d (nullable) receives layers.back().  All intermediate spectra stay resident. */
+int aefft_net_forward(aefft_net* net, const float* frames_d, float* recon_d);
+/* fft_l=1 semantics (:1347,1357,1361): coordinate-space copy of reference layer index `layer`
+ * (autoencoder.cpp:110-114 ordering, 0..4L) from the last forward.  out_d [B][ch][nx][ny];
+ * ch/nx/ny (nullable) receive its shape.  Pass out_d=NULL to query the shape only. */
+int aefft_net_get_layer(aefft_net* net, int layer, float* out_d, int* ch, int* nx, int* ny);
+
+/* fft_backproplib.cu:1381-1511 `backprop_fft` burst on pair l, using the spectra of the last
+ * forward as in / expout(=in) / out (autoencoder.cpp:169,194): zeroes the momentum (:1420-1423),
+ * del = 0.1*del0 (:1445), n_iter iterations (reference: 100, :1446) of gradient -> update ->
+ * re-forward -> mse.  mse_h (nullable) receives n_iter+1 values (initial, then one per
+ * iteration, :1440,1463); blocks until done when mse_h != NULL. */
+int aefft_net_train_pair(aefft_net* net, int l, int n_iter, float del0, int maxdiff, int sym, float* mse_h);
+
+/* One data-parallel training step = forward + ONE loop-body iteration for every pair
+ * (SURVEY 8d "one frame fwd+bwd"), split so the caller can all-reduce in between:
+ *   step_grad : forward, then per pair the batch-mean gradient, C2R, shrink -> packed buffer
+ *               [dck | dfk | db | dp] per pair, pairs concatenated; plus per-pair pre-update MSE.
+ *   (caller: all-reduce SUM of aefft_net_grad_buffer over ranks)
+ *   step_apply: gradients * grad_scale (1/world_size), update, new spectra, re-forward of each
+ *               pair, post-update MSE.  mse_d (nullable): [L] floats on the device.
+ * Momentum persists across steps (reset with aefft_net_reset_momentum). */
+int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
+int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
+int aefft_net_step_apply(aefft_net* net, float del0, int maxdiff, int sym, float grad_scale, float* mse_d);
+int aefft_net_reset_momentum(aefft_net* net);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* Per-kernel HIP event timing on the context stream (bench.py's roofline figure).  With
+ * enable=1 every kernel launch is bracketed by hipEvents recorded on the stream it runs on.
+ * aefft_prof_read synchronises and returns, for kernel id `kid` (0..aefft_prof_count()-1,
+ * named by aefft_prof_name), launches, total milliseconds and total ALGORITHMIC bytes
+ * (unique tensors entering + leaving each launch) since the last reset. */
+int aefft_prof_enable(aefft_ctx* ctx, int enable);
+int aefft_prof_count(void);
+const char* aefft_prof_name(int kid);
+int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes);
+int aefft_prof_reset(aefft_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEFFT_H */

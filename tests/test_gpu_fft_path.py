@@ -1,0 +1,311 @@
+"""GPU parity tests of the FFT-mode path, through the C ABI (include/aefft.h), against the
+oracle (oracle/np_ref.py, float64 master) on the same seeded inputs, the committed golden
+vectors, and size-independent properties at BASELINE sizes.
+
+Stated float32 tolerances: tensors |d| <= 1e-4*max|ref|; kernels after a step
+|d| <= 1e-6 + 1e-4*|dw|... expressed here relative to max|dw|; MSE |d| <= 1e-5*max(1,mse) is
+loosened to 1e-4 relative because the MSE itself is a float32 sum of ~1e5 terms."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import np_ref as R
+
+pytestmark = pytest.mark.gpu
+aefft = importlib.import_module("autoencoder-fft_amd")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fft_path.npz")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aefft.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(got, ref):
+    got = np.asarray(got); ref = np.asarray(ref)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
+# transforms
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Nx,Ny,planes", [(8, 8, 3), (16, 8, 2), (8, 32, 5), (32, 32, 7), (64, 64, 3), (128, 64, 2),
+                                          (64, 256, 2), (256, 256, 3), (512, 512, 2), (1024, 1024, 1), (2048, 512, 1),
+                                          (512, 2048, 1)])
+def test_r2c_c2r(ctx, Nx, Ny, planes):
+    rng = np.random.default_rng(Nx * 7 + Ny)
+    x = np.floor(rng.uniform(0, 256, (planes, Nx, Ny))).astype(np.float32)
+    X = ctx.r2c(ctx.dev(x))
+    ref = R.fft(x)
+    assert relerr(host(X), ref) < 2e-6          # far inside the 1e-4 budget: float32 FFT round-off only
+    # inverse of a NOT exactly Hermitian spectrum (gradient spectra are Hermitian only up to rounding)
+    Z = ref + 1e-3 * np.abs(ref).max() * (rng.normal(size=ref.shape) + 1j * rng.normal(size=ref.shape))
+    y = ctx.c2r(ctx.dev(Z), Ny)
+    assert relerr(host(y), R.fft_inv(Z, Nx, Ny)) < 5e-6
+    yu = ctx.c2r(ctx.dev(Z), Ny, scale=1.0)     # the unnormalised C2R of fft_backproplib.cu:1219
+    assert relerr(host(yu), R.c2r_unnorm(Z, Nx, Ny)) < 5e-6
+
+
+@pytest.mark.parametrize("N,s", [(32, 2), (64, 4), (256, 2), (512, 2), (128, 8)])
+def test_pool_and_fused_forms(ctx, N, s):
+    rng = np.random.default_rng(N + s)
+    x = np.floor(rng.uniform(0, 256, (3, N, N))).astype(np.float32)
+    X = R.fft(x)
+    down, nx, ny = R.pool_fft(X, N, N, s)
+    Xd, gx, gy = ctx.pool(ctx.dev(X), N, s)
+    assert (gx, gy) == (nx, ny) and relerr(host(Xd), down) == 0.0            # pure index remap: exact
+    up, ux, uy = R.pool_fft(down, nx, ny, -s)
+    Xu, gx, gy = ctx.pool(ctx.dev(down), ny, -s)
+    assert (gx, gy) == (ux, uy) and np.array_equal(host(Xu), up.astype(np.complex64))
+    # fused: r2c+crop and zero-pad+c2r
+    assert relerr(host(ctx.r2c_pool(ctx.dev(x), s)), down) < 2e-6
+    y = ctx.unpool_c2r(ctx.dev(down), ny, -s, 1.0 / (N * N))
+    assert relerr(host(y), R.fft_inv(up, N, N)) < 5e-6
+
+
+def test_pool_rejects_bad_sizes(ctx):
+    X = ctx.dev(np.zeros((1, 16, 9), np.complex64))
+    with pytest.raises(aefft.AefftError):
+        ctx.pool(X, 16, 3)           # not a power of two (SURVEY B-4)
+    with pytest.raises(aefft.AefftError):
+        ctx.pool(X, 16, 4)           # 16/4 < 8
+    with pytest.raises(aefft.AefftError):
+        ctx.r2c(ctx.dev(np.zeros((1, 12, 12), np.float32)))
+
+
+@pytest.mark.parametrize("N,Nk,Nl", [(16, 5, 5), (32, 3, 3), (64, 5, 3), (128, 7, 7)])
+def test_kernel_spectrum_and_export(ctx, N, Nk, Nl):
+    rng = np.random.default_rng(N + Nk)
+    c = rng.uniform(-3, 3, (4, 3, Nk, Nl)).astype(np.float32)
+    K = ctx.kernel_spectrum(ctx.dev(c), N, N)
+    assert relerr(host(K), R.kernel_spectrum(c, N, N)) < 2e-6
+    back = ctx.kernel_export(K, Nk, Nl, N)
+    assert np.abs(host(back) - c).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+# Hadamard contraction, gradient, mse, update
+# ------------------------------------------------------------------------------------------
+def _pair(rng, dD, dM, N, Nk, B):
+    xs = np.floor(rng.uniform(0, 256, (B, dD, N, N)))
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)).astype(np.float32).astype(np.float64)
+    f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32).astype(np.float64)
+    b = rng.uniform(-1, 1, dM).astype(np.float32).astype(np.float64)
+    p = rng.uniform(-1, 1, dD).astype(np.float32).astype(np.float64)
+    return xs, c, f, b, p
+
+
+@pytest.mark.parametrize("dD,dM,N,B", [(3, 8, 16, 1), (1, 4, 32, 3), (8, 16, 16, 5), (3, 10, 64, 2), (5, 3, 16, 4), (16, 32, 8, 2)])
+def test_conv(ctx, dD, dM, N, B):
+    rng = np.random.default_rng(dD * 100 + dM)
+    xs, c, f, b, p = _pair(rng, dD, dM, N, 5, B)
+    X = R.fft(xs); Cs = R.kernel_spectrum(c, N, N)
+    ref = np.stack([R.conv_k(X[i], Cs, b, N, N) for i in range(B)])
+    O = ctx.conv(ctx.dev(X), ctx.dev(Cs), ctx.dev(b), N)
+    assert relerr(host(O), ref) < 5e-6
+    # linearity of the contraction (size-independent property)
+    O2 = ctx.conv(ctx.dev(2 * X), ctx.dev(Cs), ctx.dev(0 * b), N)
+    O0 = ctx.conv(ctx.dev(X), ctx.dev(Cs), ctx.dev(0 * b), N)
+    assert relerr(host(O2), 2 * host(O0)) < 1e-6
+
+
+@pytest.mark.parametrize("dD,dM,N,B", [(3, 4, 16, 1), (2, 5, 32, 1), (3, 8, 16, 4), (8, 16, 16, 3), (1, 3, 64, 2)])
+def test_gradient_and_mse(ctx, dD, dM, N, B):
+    rng = np.random.default_rng(dD * 31 + dM + N)
+    xs, c, f, b, p = _pair(rng, dD, dM, N, 5, B)
+    outs = xs + rng.uniform(-20, 20, xs.shape)
+    tgt = xs + rng.uniform(-5, 5, xs.shape)                 # expout need not equal in (fft_backproplib.h:11)
+    X, T, O = R.fft(xs), R.fft(tgt), R.fft(outs)
+    Cs, Fs = R.kernel_spectrum(c, N, N), R.kernel_spectrum(f, N, N)
+    per = [R.gradient_k_io(X[i], T[i], O[i], Cs, Fs, b, N, N) for i in range(B)]
+    ref = [sum(t) / B for t in zip(*per)]
+    got = ctx.gradient(ctx.dev(X), ctx.dev(T), ctx.dev(O), ctx.dev(Cs), ctx.dev(Fs), ctx.dev(b), N)
+    for g, r in zip(got, ref):
+        assert relerr(host(g), r) < 2e-5
+    mse = ctx.mse(ctx.dev(T), ctx.dev(O), dM, N)
+    mref = np.mean([R.mse_fft(T[i], O[i], dM, dD, N, N) for i in range(B)])
+    assert abs(host(mse)[0] - mref) < 1e-5 * max(1, mref)
+
+
+@pytest.mark.parametrize("maxdiff", [0, 1])
+@pytest.mark.parametrize("dD,dM,N,Nk", [(3, 4, 16, 5), (2, 3, 32, 3)])
+def test_update(ctx, dD, dM, N, Nk, maxdiff):
+    rng = np.random.default_rng(5 + dD + maxdiff)
+    xs, c, f, b, p = _pair(rng, dD, dM, N, Nk, 1)
+    outs = xs + rng.uniform(-20, 20, xs.shape)
+    X, O = R.fft(xs[0]), R.fft(outs[0])
+    Cs, Fs = R.kernel_spectrum(c, N, N), R.kernel_spectrum(f, N, N)
+    dc, df, db, dp = R.gradient_k_io(X, X, O, Cs, Fs, b, N, N)
+    z = lambda a: np.zeros_like(a)
+    mom = [0.01 * rng.normal(size=a.shape) for a in (c, f, b, p)]
+    ref = R.backprop(c, f, b, p, dc, df, db, dp, *mom, N, N, 0.02, maxdiff)
+    t = [ctx.dev(a) for a in (c, f, b, p, Cs, Fs, dc, df, db, dp, *mom)]
+    ctx.update(*t, N, 0.02, maxdiff)
+    names = ["c", "f", "b", "p", "Dc", "Df", "Db", "Dp"]
+    got = dict(zip(["c", "f", "b", "p", "C", "F"], t[:6])); got.update(dict(zip(["Dc", "Df", "Db", "Dp"], t[10:])))
+    refd = dict(zip(names + ["C", "F"], ref))
+    for k in names:
+        dw = max(np.abs(refd[k] - dict(c=c, f=f, b=b, p=p, Dc=mom[0], Df=mom[1], Db=mom[2], Dp=mom[3])[k]).max(), 1e-12)
+        assert np.abs(host(got[k]) - refd[k]).max() < 1e-6 + 1e-3 * dw, k
+    assert relerr(host(got["C"]), refd["C"]) < 5e-6 and relerr(host(got["F"]), refd["F"]) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------
+# resident network vs oracle and golden vectors
+# ------------------------------------------------------------------------------------------
+def _golden_net(ctx, g, tag, D, N, maps, Nk, s, B=1):
+    L = len(maps)
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l in range(L):
+        net.set_pair(l, g[f"{tag}_c{l}"], g[f"{tag}_b{l}"], g[f"{tag}_c{2 * L - 1 - l}"], g[f"{tag}_b{2 * L - 1 - l}"])
+    return net
+
+
+@pytest.mark.parametrize("tag,D,N,maps,Nk,s", [("A", 3, 16, [4], 5, 1), ("B", 3, 32, [4, 6], 3, 2)])
+def test_golden_forward_and_bursts(ctx, tag, D, N, maps, Nk, s):
+    g = np.load(GOLD)
+    L = len(maps)
+    x = g[f"{tag}_x"]
+    for n_l in range(L):
+        for md in (0, 1):
+            net = _golden_net(ctx, g, tag, D, N, maps, Nk, s)
+            recon = ctx.empty(1, D, N, N)
+            net.forward(ctx.dev(x[None]), recon)
+            if n_l == 0 and md == 0:
+                for l in range(4 * L + 1):
+                    ref = g[f"{tag}_layer{l}"]
+                    assert relerr(host(net.get_layer(l))[0], ref) < TOL, l
+                assert relerr(host(recon)[0], g[f"{tag}_layer{4 * L}"]) < TOL
+            mse = net.train_pair(n_l, 3, 0.2, maxdiff=md)
+            c, b, f, p = net.get_pair(n_l)
+            pre = f"{tag}_burst{n_l}_md{md}_"
+            c0 = g[f"{tag}_c{n_l}"]
+            dw = np.abs(g[pre + "c"] - c0).max()
+            for a, k in ((c, "c"), (f, "f"), (b, "b"), (p, "p")):
+                assert np.abs(a - g[pre + k]).max() < 1e-6 + 2e-3 * dw, (k, np.abs(a - g[pre + k]).max(), dw)
+            assert np.allclose(mse, g[pre + "mse"], rtol=1e-4), (mse, g[pre + "mse"])
+            net.close()
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_step_equals_oracle_batch_iteration(ctx, B):
+    """aefft_net_step_grad / step_apply == oracle batch_train_iter for every pair (build-defined
+    batch mean); B=1 is the reference loop body."""
+    rng = np.random.default_rng(77 + B)
+    D, N, maps, Nk, s = 3, 32, [4, 6], 5, 2
+    L = len(maps)
+    xs = np.floor(rng.uniform(0, 256, (B, D, N, N)))
+    ws = []
+    dD = D
+    for dM in maps:
+        _, c, f, b, p = _pair(rng, dD, dM, 8, Nk, 1)
+        ws.append((c, b, f, p)); dD = dM
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(ws):
+        net.set_pair(l, *w)
+    net_c = [w[0] for w in ws] + [w[2] for w in ws[::-1]]
+    net_b = [w[1] for w in ws] + [w[3] for w in ws[::-1]]
+    sp = [R.autoenc_fft(xs[i], net_c, net_b, [s] * L + [-s] * L) for i in range(B)]
+    recon = ctx.empty(B, D, N, N)
+    net.step_grad(ctx.dev(xs), recon)
+    for i in range(B):
+        assert relerr(host(recon)[i], sp[i][0][-1]) < TOL
+    gbuf = host(net.grad_buffer()).copy()
+    mse = ctx.empty(L)
+    net.step_apply(0.2, 0, 0, 1.0, mse)
+    off = 0
+    for l in range(L):
+        c, b, f, p = ws[l]
+        dM, dDl = c.shape[:2]
+        Xs = [sp[i][2][2 * l + 1] for i in range(B)]
+        Os = [sp[i][2][4 * L - 1 - 2 * l] for i in range(B)]
+        cf = sp[0][1]
+        z = lambda a: np.zeros_like(a)
+        r = R.batch_train_iter(Xs, Xs, Os, cf[l], cf[2 * L - 1 - l], c, f, b, p, (z(c), z(f), z(b), z(p)), 0.02)
+        nk = c.size
+        for seg, ref in zip((gbuf[off:off + nk], gbuf[off + nk:off + 2 * nk], gbuf[off + 2 * nk:off + 2 * nk + dM],
+                             gbuf[off + 2 * nk + dM:off + 2 * nk + dM + dDl]), r["grads"]):
+            assert relerr(seg, ref.ravel()) < 5e-5
+        off += 2 * nk + dM + dDl
+        c2, b2, f2, p2 = net.get_pair(l)
+        dw = np.abs(r["c"] - c).max()
+        for a, k in ((c2, "c"), (f2, "f"), (b2, "b"), (p2, "p")):
+            assert np.abs(a - r[k]).max() < 1e-6 + 1e-3 * dw, k
+        assert abs(host(mse)[l] - r["mse"]) < 1e-4 * max(1, r["mse"])
+    net.close()
+
+
+def test_spectra_store_load_roundtrip(ctx):
+    """net_cfreq semantics: store_cfreq / load_cfreq (fft_backproplib.cu:1117-1141)."""
+    rng = np.random.default_rng(3)
+    _, c, f, b, p = _pair(rng, 3, 4, 16, 5, 1)
+    net = aefft.Net(ctx, 3, 16, 16, [4], 5, 1, batch=1)
+    net.set_pair(0, c, b, f, p)
+    Cs, Fs = net.store_spectra(0)
+    assert relerr(Cs, R.kernel_spectrum(c, 16, 16)) < 2e-6 and relerr(Fs, R.kernel_spectrum(f, 16, 16)) < 2e-6
+    net2 = aefft.Net(ctx, 3, 16, 16, [4], 5, 1, batch=1)
+    net2.load_spectra(0, Cs, b, Fs, p)
+    c2, b2, f2, p2 = net2.get_pair(0)
+    assert np.abs(c2 - c).max() < 1e-5 and np.abs(f2 - f).max() < 1e-5 and np.array_equal(b2, b.astype(np.float32))
+    x = ctx.dev(np.floor(rng.uniform(0, 256, (1, 3, 16, 16))))
+    r1, r2 = ctx.empty(1, 3, 16, 16), ctx.empty(1, 3, 16, 16)
+    net.forward(x, r1); net2.forward(x, r2)
+    assert np.array_equal(host(r1), host(r2))
+    net.close(); net2.close()
+
+
+def test_train_requires_forward(ctx):
+    net = aefft.Net(ctx, 3, 16, 16, [4], 5, 1, batch=1)
+    with pytest.raises(aefft.AefftError):
+        net.train_pair(0, 1, 0.2)
+    with pytest.raises(aefft.AefftError):
+        net.step_apply(0.2)
+    net.close()
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE-size properties (no oracle run at these sizes)
+# ------------------------------------------------------------------------------------------
+def test_full_size_roundtrip_parseval_and_delta_identity(ctx):
+    """512x512, 4 pairs (cfg3 shape, B=2): r2c->c2r identity, Parseval, and delta kernels make
+    the s=1 autoencoder the identity divided by prod(dM*dD) (conv_k divides by the output count)."""
+    import torch
+    rng = np.random.default_rng(9)
+    N, B, D = 512, 2, 3
+    x = np.floor(rng.uniform(0, 256, (B, D, N, N))).astype(np.float32)
+    xd = ctx.dev(x)
+    X = ctx.r2c(xd)
+    assert relerr(host(ctx.c2r(X, N)), x) < 2e-6
+    Xh = host(X).astype(np.complex128)
+    w = np.full(N // 2 + 1, 2.0); w[0] = w[-1] = 1.0
+    assert abs((np.abs(Xh) ** 2 * w).sum() / (N * N) / (x.astype(np.float64) ** 2).sum() - 1) < 1e-6
+    maps = [8, 16, 32, 64]
+    net = aefft.Net(ctx, D, N, N, maps, 5, 2, batch=B)
+    dD = D; fac = 1.0
+    for l, dM in enumerate(maps):
+        c = np.zeros((dM, dD, 5, 5), np.float32); f = np.zeros((dD, dM, 5, 5), np.float32)
+        for d in range(dD):
+            c[d, d, 2, 2] = 1; f[d, d, 2, 2] = 1           # channel d passes through map d
+        net.set_pair(l, c, np.zeros(dM, np.float32), f, np.zeros(dD, np.float32))
+        fac *= dM * dD; dD = dM
+    recon = ctx.empty(B, D, N, N)
+    net.forward(xd, recon)
+    # band-limit the reference the same way the 4 poolings do: keep the lowest 32x32 frequencies
+    Xl = R.fft(x[0].astype(np.float64))
+    low, nx, ny = Xl, N, N
+    for _ in maps:
+        low, nx, ny = R.pool_fft(low, nx, ny, 2)
+    for _ in maps:
+        low, nx, ny = R.pool_fft(low, nx, ny, -2)
+    ref = R.fft_inv(low, N, N) / fac
+    assert relerr(host(recon)[0], ref) < TOL
+    net.close()

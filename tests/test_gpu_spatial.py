@@ -1,0 +1,94 @@
+"""GPU parity tests of the spatial-mode path (Conv_gpu / backprop_gpu / backprop_gpu_cc semantics)
+through the C ABI against oracle/np_spatial.py (cross-pinned to the compiled CPU reference)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cpu
+import np_spatial as S
+
+pytestmark = pytest.mark.gpu
+aefft = importlib.import_module("autoencoder-fft_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aefft.Context(0)
+    yield c
+    c.close()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _case(rng, dD, dM, N, Nk, B):
+    x = np.floor(rng.uniform(0, 256, (B, dD, N, N))).astype(np.float32)
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)).astype(np.float32); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+    b = rng.uniform(-1, 1, dM).astype(np.float32); p = rng.uniform(-1, 1, dD).astype(np.float32)
+    return x, c, b, f, p
+
+
+@pytest.mark.parametrize("dD,dM,N,Nk,B", [(1, 4, 128, 3, 1), (3, 10, 32, 5, 2), (2, 3, 17, 7, 1), (8, 16, 16, 5, 3)])
+def test_conv_gpu_semantics(ctx, dD, dM, N, Nk, B):
+    x, c, b, f, p = _case(np.random.default_rng(dD + dM + N), dD, dM, N, Nk, B)
+    got = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b)))
+    for i in range(B):
+        ref = S.conv(x[i], c, b)
+        assert np.abs(got[i] - ref).max() < 1e-5 * max(1, np.abs(ref).max())
+
+
+def test_conv_cpu_semantics_matches_compiled_reference(ctx):
+    """cpu_semantics=1 reproduces netlib.cpp Conv; checked against the compiled reference when present."""
+    L = cpu.reference() or cpu.port()
+    x, c, b, f, p = _case(np.random.default_rng(4), 3, 4, 20, 5, 1)
+    got = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b), semantics="cpu"))[0]
+    ref = L.conv(x[0], c, b)
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tied", [False, True])
+@pytest.mark.parametrize("dD,dM,N,Nk,B", [(1, 4, 32, 3, 1), (3, 5, 16, 5, 1), (2, 3, 16, 3, 3)])
+def test_backprop_gpu(ctx, dD, dM, N, Nk, B, tied):
+    rng = np.random.default_rng(dD * 7 + dM + int(tied))
+    x, c, b, f, p = _case(rng, dD, dM, N, Nk, B)
+    hin = np.stack([S.conv(x[i], c, b) for i in range(B)]).astype(np.float32)
+    out = np.stack([S.conv(hin[i], f, p) for i in range(B)]).astype(np.float32)
+    mom = [0.01 * rng.normal(size=a.shape).astype(np.float32) for a in (c, b, f, p)]       # dc, db, df, dp
+    ref = S.backprop_gpu(list(x), list(out), list(hin), c, b, f, p, mom[0], mom[1], mom[2], mom[3], 0.2, 0.9,
+                         tied=tied, B_mean=True)
+    t = [ctx.dev(a) for a in (x, out, hin, c, b, f, p)]
+    tm = [ctx.dev(a) for a in mom]
+    tg = [ctx.dev(np.zeros_like(a)) for a in (c, b, f, p)]
+    ctx.backprop_spatial(*t, tm, tg, 0.2, 0.9, tied=tied)
+    names = ["c", "b", "f", "p", "dc", "db", "df", "dp", "ddc", "ddb", "ddf", "ddp"]
+    got = dict(zip(names, [host(a) for a in (t[3], t[4], t[5], t[6], *tm, *tg)]))
+    refd = dict(zip(names, ref))
+    for k in names:
+        if refd[k] is None or (tied and k == "df"):
+            continue
+        scale = max(np.abs(refd[k]).max(), 1e-6) if k.startswith("d") else max(np.abs(refd["dc"]).max(), 1e-6)
+        assert np.abs(got[k] - refd[k]).max() < 1e-6 + 1e-3 * scale, k
+    if tied:
+        assert np.array_equal(got["f"], np.transpose(got["c"], (1, 0, 2, 3)))    # backproplib.cu:622
+
+
+def test_gradient_cpu_semantics_vs_compiled_reference(ctx):
+    """lo=1 / CPU geometry: the device gradient equals what the compiled CPU backprop applies."""
+    L = cpu.reference() or cpu.port()
+    rng = np.random.default_rng(21)
+    dD, dM, N, Nk = 2, 3, 12, 5
+    x = rng.uniform(0, 16, (1, dD, N, N)).astype(np.float32); out = (x + rng.uniform(-2, 2, x.shape)).astype(np.float32)
+    hin = rng.uniform(-4, 4, (1, dM, N, N)).astype(np.float32); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+    dele = 1e-12
+    z = np.zeros((dM, dD, Nk, Nk), np.float32)
+    c2, b2, f2, p2 = L.backprop(x[0], out[0], hin[0], z, np.zeros(dM, np.float32), f, np.zeros(dD, np.float32), dele)
+    t = [ctx.dev(a) for a in (x, out, hin, z, np.zeros(dM), f, np.zeros(dD))]
+    tm = [ctx.dev(np.zeros_like(a)) for a in (z, np.zeros(dM), f, np.zeros(dD))]
+    tg = [ctx.dev(np.zeros_like(a)) for a in (z, np.zeros(dM), f, np.zeros(dD))]
+    ctx.backprop_spatial(*t, tm, tg, 0.0, 0.0, semantics="cpu")
+    ref = -c2.astype(np.float64) * 10 / dele
+    assert np.abs(host(tg[0]) - ref).max() < 1e-4 * np.abs(ref).max()
+    refb = -b2.astype(np.float64) * 10 / dele
+    assert np.abs(host(tg[1]) - refb).max() < 1e-4 * np.abs(refb).max()

@@ -180,3 +180,49 @@ def test_batch_of_one_equals_reference_iteration():
     for k in ("c", "f", "b", "p"):
         assert np.allclose(r1[k], r2[k], rtol=0, atol=1e-12)
     assert r2["mse"] == pytest.approx(r1["mse"][1])
+
+
+# ---- spatial-mode restatement (oracle/np_spatial.py) vs the compiled CPU reference ----------
+import np_spatial as S
+
+
+def test_spatial_conv_cpu_semantics_equals_compiled_conv():
+    L = _ref_or_port()
+    rng = np.random.default_rng(11)
+    for (dD, dM, N, Nk) in ((2, 3, 12, 3), (3, 2, 14, 5), (1, 2, 16, 7)):
+        x = np.floor(rng.uniform(0, 256, (dD, N, N))); c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)); b = rng.uniform(-1, 1, dM)
+        ref = L.conv(x, c, b)
+        got = S.conv(x.astype(np.float32), c.astype(np.float32), b.astype(np.float32), cpu_semantics=True)
+        assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_spatial_gradients_cpu_semantics_equal_compiled_backprop():
+    """np_spatial.gradients(lo=1, cpu_geom) == the gradient the compiled CPU backprop applies
+    (read back from a tiny step on zero weights; f untouched so no in-loop update effect)."""
+    L = _ref_or_port()
+    rng = np.random.default_rng(12)
+    for (dD, dM, N, Nk) in ((2, 3, 10, 3), (2, 2, 12, 5)):
+        x = rng.uniform(0, 16, (dD, N, N)).astype(np.float32); out = (x + rng.uniform(-2, 2, x.shape)).astype(np.float32)
+        hin = rng.uniform(-4, 4, (dM, N, N)).astype(np.float32)
+        f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+        dele = 1e-12
+        z = np.zeros((dM, dD, Nk, Nk), np.float32)
+        c2, b2, f2, p2 = L.backprop(x, out, hin, z, np.zeros(dM, np.float32), f, np.zeros(dD, np.float32), dele)
+        assert np.array_equal(f2, f)
+        c3, b3, f3, p3 = L.backprop(x, out, hin, z, np.zeros(dM, np.float32), np.zeros_like(f), np.zeros(dD, np.float32), dele)
+        gc, gf, gb, gp = S.gradients(x, out, hin, f, lo=1, cpu_geom=True)
+        for got, ref in ((gc, -c2.astype(np.float64) * 10 / dele), (gf, -f3.astype(np.float64) * 10 / dele),
+                         (gb, -b2.astype(np.float64) * 10 / dele), (gp, -p2.astype(np.float64) * 10 / dele)):
+            assert np.abs(ref).max() < 10
+            assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
+
+
+def test_spatial_gpu_conv_matches_fft_mode_interior_3x3():
+    """Appendix B-10: for 3x3 all modes are centred; FFT mode (circular) and spatial GPU mode
+    (zero pad) agree away from the 1-pixel border, both dividing the input by dM."""
+    rng = np.random.default_rng(13)
+    dD, dM, N = 2, 3, 16
+    x = rng.uniform(0, 255, (dD, N, N)); c = rng.uniform(-1, 1, (dM, dD, 3, 3)); b = rng.uniform(-1, 1, dM)
+    hs = S.conv(x, c, b)
+    hf = R.fft_inv(R.conv_k(R.fft(x), R.kernel_spectrum(c, N, N), b, N, N), N, N)
+    assert np.abs(hs - hf)[:, 1:-1, 1:-1].max() < 1e-9
