@@ -33,7 +33,7 @@ _vp, _fp, _i, _l, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float   # 
 
 # name -> (restype, argtypes); must list every symbol declared in include/aefft.h
 SIGNATURES = {
-    "aefft_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "aefft_ctx_create": (_i, [C.POINTER(_vp), _i, _vp, _i]),
     "aefft_ctx_destroy": (None, [_vp]),
     "aefft_last_error": (C.c_char_p, [_vp]),
     "aefft_sync": (_i, [_vp]),
@@ -112,7 +112,7 @@ class Context:
         self.L = lib()
         h = C.c_void_p()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if use_torch_stream else None
-        rc = self.L.aefft_ctx_create(C.byref(h), self.device, stream)
+        rc = self.L.aefft_ctx_create(C.byref(h), self.device, stream, 0 if use_torch_stream else 1)
         if rc != OK:
             raise AefftError(f"aefft_ctx_create failed with code {rc}")
         self.h = h

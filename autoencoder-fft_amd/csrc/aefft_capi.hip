@@ -96,7 +96,7 @@ struct Bracket {
 
 extern "C" const char* aefft_version(void) { return "aefft 0.1 (gfx950)"; }
 
-extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream)
+extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, int create_stream)
 {
     if (!out) return AEFFT_EINVAL;
     *out = nullptr;
@@ -105,7 +105,7 @@ extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream)
     aefft_ctx* ctx = new aefft_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
-    if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!create_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
         ctx->own_stream = true;

@@ -40,9 +40,10 @@ enum {
 };
 
 /* ---- context ------------------------------------------------------------------------------- */
-/* `hip_stream`: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let the
- * context create its own non-blocking stream. */
-int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream);
+/* create_stream = 0: enqueue on `hip_stream`, a hipStream_t owned by the caller (e.g. torch's
+ * current stream; NULL is the legacy default stream).  create_stream = 1: the context creates
+ * and owns a non-blocking stream (`hip_stream` ignored). */
+int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, int create_stream);
 void aefft_ctx_destroy(aefft_ctx* ctx);
 const char* aefft_last_error(const aefft_ctx* ctx);
 int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the context stream */

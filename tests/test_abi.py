@@ -46,7 +46,7 @@ def test_no_gpu_fails_loudly(built):
         aefft.Context()
     import ctypes as C
     h = C.c_void_p()
-    assert built.aefft_ctx_create(C.byref(h), 0, None) == aefft.EHIP and not h.value
+    assert built.aefft_ctx_create(C.byref(h), 0, None, 1) == aefft.EHIP and not h.value
 
 
 def test_product_does_not_touch_oracle():

@@ -62,7 +62,7 @@ def test_pool_and_fused_forms(ctx, N, s):
     X = R.fft(x)
     down, nx, ny = R.pool_fft(X, N, N, s)
     Xd, gx, gy = ctx.pool(ctx.dev(X), N, s)
-    assert (gx, gy) == (nx, ny) and relerr(host(Xd), down) == 0.0            # pure index remap: exact
+    assert (gx, gy) == (nx, ny) and np.array_equal(host(Xd), down.astype(np.complex64))   # pure index remap: exact
     up, ux, uy = R.pool_fft(down, nx, ny, -s)
     Xu, gx, gy = ctx.pool(ctx.dev(down), ny, -s)
     assert (gx, gy) == (ux, uy) and np.array_equal(host(Xu), up.astype(np.complex64))
@@ -130,7 +130,9 @@ def test_gradient_and_mse(ctx, dD, dM, N, B):
     ref = [sum(t) / B for t in zip(*per)]
     got = ctx.gradient(ctx.dev(X), ctx.dev(T), ctx.dev(O), ctx.dev(Cs), ctx.dev(Fs), ctx.dev(b), N)
     for g, r in zip(got, ref):
-        assert relerr(host(g), r) < 2e-5
+        # the float32 replay of the reference arithmetic itself sits at 5e-5 here (rounding of the DC bins
+        # of O and T before the subtraction), so the stated 1e-4 is the meaningful bound
+        assert relerr(host(g), r) < TOL
     mse = ctx.mse(ctx.dev(T), ctx.dev(O), dM, N)
     mref = np.mean([R.mse_fft(T[i], O[i], dM, dD, N, N) for i in range(B)])
     assert abs(host(mse)[0] - mref) < 1e-5 * max(1, mref)
