@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s forward+backward of the FFT-mode autoencoder training path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], SURVEY 8d "config 3"): 512x512 RGB frames, 4 encoder/decoder
+pairs (3->8->16->32->64 maps, 5x5 kernels), FFT mode, 32 synthetic frames per GPU resident in HBM.
+Default variant P2 = the reference's own pooling (New_Layer_Param.txt: scale 2 per layer);
+`--variant p1` is the no-pooling, honestly HBM-bound variant.
+
+One step = 1x autoenc_fft over the batch + for EVERY pair one backprop_fft loop-body iteration
+(gradient -> C2R -> shrink -> [all-reduce of the packed kernel-support gradients when N>1] ->
+update -> pad -> R2C -> re-forward of the pair -> MSE).  Nothing is skipped or cached.
+
+Prints ONE JSON line (rank 0): metric/value per the driver contract, plus
+  "roofline":     the dominant kernel's algorithmic bytes / its HIP-event-timed duration vs 8 TB/s
+  "cpu_baseline": the reference's CPU path (oracle/_ref when built, else the C port) timed on this
+                  host on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU (weak scaling)")
+    ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_frames(torch, B, D, N, device, first_index):
+    """per-pixel floor(U[0,256)) + a smooth low-frequency component, seed = 1000 + frame index."""
+    out = torch.empty(B, D, N, N, dtype=torch.float32, device=device)
+    i = torch.arange(N, device=device, dtype=torch.float32)[:, None] / N
+    j = torch.arange(N, device=device, dtype=torch.float32)[None, :] / N
+    for b in range(B):
+        g = torch.Generator(device=device); g.manual_seed(1000 + first_index + b)
+        noise = torch.floor(torch.rand(D, N, N, generator=g, device=device) * 256)
+        for d in range(D):
+            smooth = 64 * (1 + torch.sin(2 * torch.pi * (i * (d + 1) + 0.3))) * (1 + torch.cos(2 * torch.pi * j * 2)) / 2
+            out[b, d] = torch.floor(0.5 * noise[d] + smooth)
+    return out
+
+
+def init_weights(net, np, rmax=3.0):
+    """U(-rmax, rmax), rmax = 3 (New_Layer_Param.txt:5), fixed seeds -> identical on every rank."""
+    for l, g in enumerate(net.dims):
+        rng = np.random.default_rng(4242 + l)
+        c = rng.uniform(-rmax, rmax, (g["dM"], g["dD"], g["Nk"], g["Nl"]))
+        f = rng.uniform(-rmax, rmax, (g["dD"], g["dM"], g["Nk"], g["Nl"]))
+        net.set_pair(l, c, rng.uniform(-rmax, rmax, g["dM"]), f, rng.uniform(-rmax, rmax, g["dD"]))
+
+
+def cpu_baseline(np, N, scale):
+    """Pair 1 of this workload (3->8 maps, 5x5) for ONE frame through the reference CPU path:
+    Pool -> Conv -> Conv -> Pool(-s) -> backprop (autoencoder.cpp:135-150,200; netlib.cpp)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu
+    L = cpu.reference() or cpu.port()
+    rng = np.random.default_rng(1)
+    dD, dM, Nk = 3, 8, 5
+    n = N // scale
+    x = np.floor(rng.uniform(0, 256, (dD, N, N))).astype(np.float32)
+    c = rng.uniform(-3, 3, (dM, dD, Nk, Nk)).astype(np.float32); f = rng.uniform(-3, 3, (dD, dM, Nk, Nk)).astype(np.float32)
+    b = rng.uniform(-3, 3, dM).astype(np.float32); p = rng.uniform(-3, 3, dD).astype(np.float32)
+    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)   # the reference prints "mse: ..."
+    try:
+        t0 = time.perf_counter()
+        pin = L.pool(x, (dD, n, n), scale)
+        h = L.conv(pin, c, b)
+        o = L.conv(h, f, p)
+        L.pool(o, (dD, N, N), -scale)
+        L.backprop(pin, o, h, c, b, f, p, 0.2)
+        dt = time.perf_counter() - t0
+    finally:
+        os.dup2(saved, 1); os.close(devnull); os.close(saved)
+    return {"value": 1.0 / dt, "unit": "frames/s (pair 1 of 4 only)", "cores": 1, "kind": L.kind,
+            "sample": f"1 frame {N}x{N}x3, pair 1 only (3->8 maps, 5x5, pool {scale}): Pool+Conv+Conv+Pool+backprop, "
+                      f"{dt:.1f} s single-threaded as the reference runs; pairs 2-4 not timed (O(K^4) nest)"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    aefft = importlib.import_module("autoencoder-fft_amd")
+    ctx = aefft.Context(local)
+    N, D, maps, Nk = a.size, 3, [8, 16, 32, 64], 5
+    s = 2 if a.variant == "p2" else 1
+    B = a.batch
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    init_weights(net, np)
+    dev = f"cuda:{local}"
+    frames = synth_frames(torch, B, D, N, dev, first_index=rank * B)      # each rank its own shard of the global batch
+    recon = torch.empty_like(frames)
+    mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
+    gbuf = net.grad_buffer()
+    del0 = 0.2                                                            # autoencoder.cpp:87
+
+    def step():
+        net.step_grad(frames, recon)
+        if world > 1:
+            dist.all_reduce(gbuf)                                         # RCCL sum of the packed kernel-support gradients
+        net.step_apply(del0, 0, 0, 1.0 / world, mse)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    mse_host = mse.cpu().numpy().tolist()
+    if not all(np.isfinite(mse_host)):
+        raise SystemExit(f"non-finite MSE {mse_host}")
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # per-kernel HIP events on the stream the kernels run on, over the same step
+        ctx.prof_enable(True); ctx.prof_reset()
+        for _ in range(3):
+            net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
+        prof = ctx.prof_read(); ctx.prof_enable(False)
+        tot = sum(v["ms"] for v in prof.values())
+        name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_bytes = dom["bytes"] / dom["launches"]
+        avg_s = dom["ms"] / dom["launches"] * 1e-3
+        ach = per_launch_bytes / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 3,
+                "algo_bytes_per_launch": per_launch_bytes, "share_of_kernel_time": dom["ms"] / tot,
+                "kernels": {k: {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] / 3,
+                                "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0}
+                            for k, v in prof.items() if v["launches"]}}
+        # whole-step view: algorithmic bytes of all launched kernel groups / wall time of the timed region
+        step_bytes = sum(v["bytes"] for v in prof.values()) / 3
+        roof["step_algo_GB"] = step_bytes / 1e9
+        roof["step_frac_of_hbm_peak"] = step_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(np, N, s if s > 1 else 2)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": world * B * a.steps / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg3-{a.variant.upper()}: {N}x{N}x3 frames, 4 pairs 3->8->16->32->64, 5x5, pool {s}/layer, FFT mode, "
+                                   f"fwd + 1 loop-body iteration per pair", "frames_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"dp{world}" + (" (RCCL all-reduce of packed kernel-support gradients)" if world > 1 else "")},
+            "mse_per_pair": mse_host,
+        }
+        if roof:
+            out["roofline"] = roof
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
