@@ -14,21 +14,26 @@ using namespace aefft;
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-enum { WS_MID = 0, WS_REAL = 1, WS_G = 2, WS_HP = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_COUNT = 10 };
+enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_PART = 10, WS_COUNT = 11 };
 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
     KID_R2C_ROWS = 0, KID_R2C_COLS, KID_C2R_COLS, KID_C2R_ROWS, KID_CONTRACT, KID_RESIZE, KID_DIFFMSE, KID_BIASGRAD,
-    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_COUNT
+    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_COUNT
 };
 
 struct ProfEvent { hipEvent_t a, b; int kid; double bytes; };
 
 struct aefft_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
+    hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
+    static const int NAUX = 4;
+    hipStream_t aux[NAUX] = {};      // side streams for independent per-pair work (created on first net)
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {};
     std::string err;
+    const float2* tw = nullptr;      // device twiddle table
     void* ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
     bool prof = false;
@@ -89,9 +94,9 @@ struct Bracket {
         if (c->used >= c->pool.size()) return;   // pool exhausted: stop recording (read() reports what it has)
         idx = (int)c->used++;
         c->pool[idx].kid = kid; c->pool[idx].bytes = bytes;
-        (void)hipEventRecord(c->pool[idx].a, c->stream);
+        (void)hipEventRecord(c->pool[idx].a, c->cur);
     }
-    ~Bracket() { if (idx >= 0) (void)hipEventRecord(ctx->pool[idx].b, ctx->stream); }
+    ~Bracket() { if (idx >= 0) (void)hipEventRecord(ctx->pool[idx].b, ctx->cur); }
 };
 
 extern "C" const char* aefft_version(void) { return "aefft 0.1 (gfx950)"; }
@@ -111,6 +116,8 @@ extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, i
         ctx->own_stream = true;
     }
     if (upload_twiddles(ctx->stream) != hipSuccess) { if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream); delete ctx; return AEFFT_EHIP; }
+    ctx->cur = ctx->stream;
+    ctx->tw = twiddle_table();
     *out = ctx;
     return AEFFT_OK;
 }
@@ -121,6 +128,8 @@ extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < WS_COUNT; ++i) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (auto& e : ctx->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) { if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); } if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -143,6 +152,7 @@ extern "C" int aefft_prof_enable(aefft_ctx* ctx, int enable)
 static int prof_collect(aefft_ctx* ctx)
 {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) if (ctx->aux[i]) HIPCHK(ctx, hipStreamSynchronize(ctx->aux[i]));
     for (size_t i = 0; i < ctx->used; ++i) {
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pool[i].a, ctx->pool[i].b));
@@ -162,7 +172,7 @@ extern "C" int aefft_prof_reset(aefft_ctx* ctx)
 }
 
 static const char* kid_names[KID_COUNT] = {"r2c_rows", "r2c_cols", "c2r_cols", "c2r_rows", "contract", "resize", "diff_mse",
-                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial"};
+                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad"};
 
 extern "C" int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes)
 {
@@ -177,7 +187,7 @@ extern "C" const char* aefft_prof_name(int kid) { return (kid >= 0 && kid < KID_
 extern "C" int aefft_prof_count(void) { return KID_COUNT; }
 
 // ------------------------------------------------------------------------------------------
-// internal op helpers (all enqueue on ctx->stream)
+// internal op helpers (all enqueue on ctx->cur)
 // ------------------------------------------------------------------------------------------
 static long bins(int Nx, int Ny) { return (long)Nx * (Ny / 2 + 1); }
 
@@ -201,12 +211,12 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
     {
         // The row and column kernels are launched inside launch_r2c; to time them separately we call it in two halves.
         Bracket br(ctx, KID_R2C_ROWS, b_in + b_mid);
-        e = launch_r2c(x, nullptr, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+        e = launch_r2c(x, nullptr, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c rows", e);
     {
         Bracket br(ctx, KID_R2C_COLS, b_mid + b_out);
-        e = launch_r2c(nullptr, X, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+        e = launch_r2c(nullptr, X, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c cols", e);
     return AEFFT_OK;
@@ -222,12 +232,12 @@ static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nx
     hipError_t e;
     {
         Bracket br(ctx, KID_C2R_COLS, b_in + b_mid);
-        e = launch_c2r(X, nullptr, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->stream);
+        e = launch_c2r(X, nullptr, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->cur);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r cols", e);
     {
         Bracket br(ctx, KID_C2R_ROWS, b_mid + b_out);
-        e = launch_c2r(nullptr, x, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->stream);
+        e = launch_c2r(nullptr, x, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->cur);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r rows", e);
     return AEFFT_OK;
@@ -238,8 +248,20 @@ static int do_contract(aefft_ctx* ctx, const Contract& q)
     // algorithmic bytes: A (R*K planes) + B (K*C planes) + Out (R*C planes), 8 B per bin
     const double bytes = ((double)q.R * q.K + (double)q.K * q.C + (double)q.R * q.C) * q.P * 8.0;
     Bracket br(ctx, KID_CONTRACT, bytes);
-    hipError_t e = launch_contract(q, ctx->stream);
+    hipError_t e = launch_contract(q, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract", e);
+    return AEFFT_OK;
+}
+
+static int do_contract2(aefft_ctx* ctx, const Contract& q0, const Contract& q1)
+{
+    const double bytes = (((double)q0.R * q0.K + (double)q0.K * q0.C + (double)q0.R * q0.C) * q0.P +
+                          ((double)q1.R * q1.K + (double)q1.K * q1.C + (double)q1.R * q1.C) * q1.P) * 8.0;
+    Contract2 qq{};
+    qq.q[0] = q0; qq.q[1] = q1; qq.n = 2;
+    Bracket br(ctx, KID_CONTRACT, bytes);
+    hipError_t e = launch_contract2(qq, ctx->cur);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract2", e);
     return AEFFT_OK;
 }
 
@@ -259,10 +281,33 @@ static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float
     return do_contract(ctx, q);
 }
 
+// conv_k whose input is the zero-pad up-sampling (pool_fft with negative scale, fft_backproplib.cu:1360 of the
+// previous decoder) of Xs [B][K][sNx][sNy/2+1]: the up-sampled tensor is never materialised.
+static int do_conv_up(aefft_ctx* ctx, const float2* Xs, const float2* W, const float* bias, float2* O, int B, int R, int K,
+                      int Nx, int Ny, int sNx, int sNy)
+{
+    if (sNx == Nx && sNy == Ny) return do_conv(ctx, Xs, W, bias, O, B, R, K, Nx, Ny);
+    const long P = bins(Nx, Ny), Ps = bins(sNx, sNy);
+    Contract q{};
+    q.A = W; q.a_r = (long)K * P; q.a_k = P;
+    q.B = Xs; q.b_k = Ps; q.b_c = (long)K * Ps;
+    q.Out = O; q.o_r = P; q.o_c = (long)R * P;
+    q.R = R; q.C = B; q.K = K; q.P = P;
+    q.preDivB = (float)R;
+    q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
+    q.upNx = Nx; q.upNy = Ny; q.upNxs = sNx; q.upNys = sNy;
+    // algorithmic bytes: the SMALL input, the weights on the support, the full output
+    const double bytes = ((double)K * B * Ps + (double)R * K * Ps + (double)R * B * P) * 8.0;
+    Bracket br(ctx, KID_CONTRACT, bytes);
+    hipError_t e = launch_contract(q, ctx->cur);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract(up)", e);
+    return AEFFT_OK;
+}
+
 static int do_resize(aefft_ctx* ctx, const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys)
 {
     Bracket br(ctx, KID_RESIZE, (double)planes * (std::min(bins(Nx, Ny), bins(Nxs, Nys)) + bins(Nxs, Nys)) * 8.0);
-    hipError_t e = launch_resize(in, out, planes, Nx, Ny, Nxs, Nys, ctx->stream);
+    hipError_t e = launch_resize(in, out, planes, Nx, Ny, Nxs, Nys, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "resize", e);
     return AEFFT_OK;
 }
@@ -274,83 +319,91 @@ static void pooled(int Nx, int Ny, int scale, int* Nxs, int* Nys)
     else { *Nxs = Nx * (-scale); *Nys = Ny * (-scale); }
 }
 
-// E = O - T (optional) and mse (optional), mean over B:  scale = 1/(2*dM*Nx*Ny*B)
-static int do_diff_mse(aefft_ctx* ctx, const float2* T, const float2* O, float2* E, float* mse, int B, int dM, int dD, int Nx, int Ny)
+// E = O - T (optional), mse (optional, ACCUMULATED into *mse: caller zeroes), es (optional, accumulated),
+// mean over B:  scale = 1/(2*dM*Nx*Ny*B)
+static int do_diff_mse(aefft_ctx* ctx, const float2* T, const float2* O, float2* E, float* mse, float* es, int B, int dM, int dD, int Nx, int Ny)
 {
-    if (mse) HIPCHK(ctx, hipMemsetAsync(mse, 0, sizeof(float), ctx->stream));
     const float scale = 1.0f / ((float)(2 * dM) * (float)Nx * (float)Ny * (float)B);
     Bracket br(ctx, KID_DIFFMSE, (double)B * dD * bins(Nx, Ny) * 8.0 * (E ? 3 : 2));
-    hipError_t e = launch_diff_mse(T, O, E, mse, B, dD, Nx, Ny, scale, ctx->stream);
+    hipError_t e = launch_diff_mse(T, O, E, mse, es, B, dD, Nx, Ny, scale, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "diff_mse", e);
     return AEFFT_OK;
 }
 
-// gradient_k_io over a batch, given E = O - Xout.  G, Hp: workspaces [B][dM][P].
-static int do_gradient(aefft_ctx* ctx, const float2* Xin, const float2* E, const float2* C, const float2* F, const float* b,
-                       float2* G, float2* Hp, float2* dc, float2* df, float* db, float* dp, int B, int dM, int dD, int Nx, int Ny)
+// gradient_k_io over a batch (fft_backproplib.cu:395-475); T = spectrum of the expected output, E = O - T.
+// The reference's four per-bin sums are re-associated so that the batch is contracted FIRST:
+//     S[d][d1]  = sum_b  (O_b[d] - T_b[d]) * conj(X_b[d1])            (dD x dD per bin; the subtraction is fused)
+//     dc[m][d]  = sum_d1 conj(F[d1][m]) * S[d1][d]      / (Norm*B)   (== conj(X) * sum_d1 E conj(F), :421-439)
+//     df[d][m]  = sum_d1 S[d][d1] * conj(C[m][d1])      / (Norm*B)   (== E * conj(sum_d1 C X),      :426-455)
+//     df[d][m](0,0) += es[d] * b[m]*Nx*Ny / (Norm*B),  es[d] = sum_b E_b[d](0,0)   (the b0 term, :448-455)
+// Same sums, different order (float32 rounding only); neither E nor the B*dM-plane intermediates of the
+// literal form are materialised.  S: workspace [dD][dD][P].  dc and df are produced by ONE launch.
+static int do_gradient(aefft_ctx* ctx, const float2* Xin, const float2* T, const float2* O, const float2* C, const float2* F,
+                       const float* b, float2* S, float2* dc, float2* df, float* db, float* dp, int B, int dM, int dD, int Nx, int Ny)
 {
     const long P = bins(Nx, Ny);
     const float norm = (float)Nx * (float)Ny;                 // fft_backproplib.cu:398
     const float Norm = norm * 2 * dM * dD * Nx * Ny;          // :399 (float arithmetic, left to right)
-    {   // G[b][m] = sum_d1 conj(F[d1][m]) * E[b][d1]
+    {
         Contract q{};
-        q.A = F; q.a_r = P; q.a_k = (long)dM * P; q.conjA = true;
-        q.B = E; q.b_k = P; q.b_c = (long)dD * P;
-        q.Out = G; q.o_r = P; q.o_c = (long)dM * P;
-        q.R = dM; q.C = B; q.K = dD; q.P = P;
-        RET_IF(do_contract(ctx, q));
-    }
-    {   // H'[b][m] = sum_d1 C[m][d1] * X[b][d1]  + b[m]*norm at DC (added after the sum, :454)
-        Contract q{};
-        q.A = C; q.a_r = (long)dD * P; q.a_k = P;
-        q.B = Xin; q.b_k = P; q.b_c = (long)dD * P;
-        q.Out = Hp; q.o_r = P; q.o_c = (long)dM * P;
-        q.R = dM; q.C = B; q.K = dD; q.P = P;
-        q.bias = b; q.biasScale = norm; q.biasAfterFirst = false;
-        RET_IF(do_contract(ctx, q));
-    }
-    {   // dc[m][d] = sum_b G[b][m] * conj(X[b][d]) / Norm   (mean over frames: / B)
-        Contract q{};
-        q.A = G; q.a_r = P; q.a_k = (long)dM * P;
+        q.A = O; q.A2 = T; q.a_r = P; q.a_k = (long)dD * P;
         q.B = Xin; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
-        q.Out = dc; q.o_r = (long)dD * P; q.o_c = P;
-        q.R = dM; q.C = dD; q.K = B; q.P = P;
-        q.postDiv = Norm * (float)B;
-        RET_IF(do_contract(ctx, q));
-    }
-    {   // df[d][m] = sum_b E[b][d] * conj(H'[b][m]) / Norm
-        Contract q{};
-        q.A = E; q.a_r = P; q.a_k = (long)dD * P;
-        q.B = Hp; q.b_k = (long)dM * P; q.b_c = P; q.conjB = true;
-        q.Out = df; q.o_r = (long)dM * P; q.o_c = P;
-        q.R = dD; q.C = dM; q.K = B; q.P = P;
-        q.postDiv = Norm * (float)B;
+        q.Out = S; q.o_r = (long)dD * P; q.o_c = P;
+        q.R = dD; q.C = dD; q.K = B; q.P = P;
         RET_IF(do_contract(ctx, q));
     }
     {
-        Bracket br(ctx, KID_BIASGRAD, (double)B * (dM + dD) * 8.0);
-        hipError_t e = launch_bias_grad(G, E, db, dp, B, dM, dD, P, norm, Norm, ctx->stream);
+        Contract q{}, r{};
+        q.A = F; q.a_r = P; q.a_k = (long)dM * P; q.conjA = true;
+        q.B = S; q.b_k = (long)dD * P; q.b_c = P;
+        q.Out = dc; q.o_r = (long)dD * P; q.o_c = P;
+        q.R = dM; q.C = dD; q.K = dD; q.P = P;
+        q.postDiv = Norm * (float)B;
+        r.A = S; r.a_r = (long)dD * P; r.a_k = P;
+        r.B = C; r.b_k = P; r.b_c = (long)dD * P; r.conjB = true;
+        r.Out = df; r.o_r = (long)dM * P; r.o_c = P;
+        r.R = dD; r.C = dM; r.K = dD; r.P = P;
+        r.postDiv = Norm * (float)B;
+        RET_IF(do_contract2(ctx, q, r));
+    }
+    {
+        Bracket br(ctx, KID_BIASGRAD, ((double)(dM * dD + dM + dD) + 2.0 * B * dD) * 8.0);
+        hipError_t e = launch_bias_grad(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "bias_grad", e);
     }
     return AEFFT_OK;
 }
 
-// unnormalised C2R of a gradient spectrum + shrink to the kernel support: g[planes][Nk][Nl]
-static int do_c2r_shrink(aefft_ctx* ctx, const float2* dspec, float* gk, float* realws, long planes, int Nx, int Ny, int Nk, int Nl)
+// unnormalised C2R of a gradient spectrum sampled on the kernel support: g[planes][Nk][Nl]
+// (== shrink_k(cufftExecC2R(d)), fft_backproplib.cu:1219-1226).  Direct pruned evaluation when the
+// support is 3x3/5x5/7x7, generic C2R + shrink otherwise.
+static int do_c2r_shrink(aefft_ctx* ctx, const float2* dspec, float* gk, float* realws, float* part, long planes, int Nx, int Ny, int Nk, int Nl, float scale = 1.0f)
 {
-    RET_IF(do_c2r(ctx, dspec, realws, planes, Nx, Ny, Nx, Ny, 1.0f));
+    if (pruned_supported(Nk, Nl, Nx, Ny)) {
+        Bracket br(ctx, KID_KGRAD, (double)planes * (bins(Nx, Ny) * 8.0 + Nk * Nl * 4.0));
+        hipError_t e = launch_kgrad(dspec, gk, part, ctx->tw, planes, Nx, Ny, Nk, Nl, scale, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "kgrad", e);
+        return AEFFT_OK;
+    }
+    RET_IF(do_c2r(ctx, dspec, realws, planes, Nx, Ny, Nx, Ny, scale));
     Bracket br(ctx, KID_SHRINK, (double)planes * Nk * Nl * 8.0);
-    hipError_t e = launch_shrink(realws, gk, planes, Nx, Ny, Nk, Nl, 1.0f, ctx->stream);
+    hipError_t e = launch_shrink(realws, gk, planes, Nx, Ny, Nk, Nl, 1.0f, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "shrink", e);
     return AEFFT_OK;
 }
 
-// pad + R2C: kernel [planes][Nk][Nl] -> spectrum [planes][Nx][Nyr]
+// pad + R2C: kernel [planes][Nk][Nl] -> spectrum [planes][Nx][Nyr]  (fft_backproplib.cu:1274-1282 / 1150-1152)
 static int do_pad_r2c(aefft_ctx* ctx, const float* k, float2* K, float* realws, long planes, int Nx, int Ny, int Nk, int Nl)
 {
+    if (pruned_supported(Nk, Nl, Nx, Ny)) {
+        Bracket br(ctx, KID_KSPEC, (double)planes * (bins(Nx, Ny) * 8.0 + Nk * Nl * 4.0));
+        hipError_t e = launch_kspec(k, K, ctx->tw, planes, Nx, Ny, Nk, Nl, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "kspec", e);
+        return AEFFT_OK;
+    }
     {
         Bracket br(ctx, KID_PAD, (double)planes * ((double)Nx * Ny + Nk * Nl) * 4.0);
-        hipError_t e = launch_pad(k, realws, planes, Nx, Ny, Nk, Nl, ctx->stream);
+        hipError_t e = launch_pad(k, realws, planes, Nx, Ny, Nk, Nl, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "pad", e);
     }
     return do_r2c(ctx, realws, K, planes, Nx, Ny, Nx, Ny);
@@ -377,13 +430,13 @@ static int do_update(aefft_ctx* ctx, float* c, float* f, float* b, float* p, con
         float* cd = (float*)small; float* fd = cd + nk; float* bd = fd + nk; float* pd = bd + dM;
         {
             Bracket br(ctx, KID_GDIFF, (double)nk * 16.0);
-            hipError_t e = launch_gradient_diff(c, f, b, p, cd, fd, bd, pd, (float*)den, dM, dD, Nk, Nl, ctx->stream);
+            hipError_t e = launch_gradient_diff(c, f, b, p, cd, fd, bd, pd, (float*)den, dM, dD, Nk, Nl, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "gradient_diff", e);
         }
         a.cd = cd; a.fd = fd; a.bd = bd; a.pd = pd;
     }
     Bracket br(ctx, KID_UPDATE, (double)dM * dD * Nk * Nl * 4.0 * 8);
-    hipError_t e = launch_update(a, ctx->stream);
+    hipError_t e = launch_update(a, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update", e);
     return AEFFT_OK;
 }
@@ -451,8 +504,8 @@ extern "C" int aefft_kernel_spectrum(aefft_ctx* ctx, const float* k_d, float* K_
     if (!ctx || !k_d || !K_d || nA <= 0 || nB <= 0 || Nk <= 0 || Nl <= 0 || Nk > Nx || Nl > Ny) return fail(ctx, AEFFT_EINVAL, "aefft_kernel_spectrum: bad argument");
     RET_IF(chk_size(ctx, Nx, Ny));
     const long planes = (long)nA * nB;
-    void* real;
-    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    void* real = nullptr;
+    if (!pruned_supported(Nk, Nl, Nx, Ny)) RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
     return do_pad_r2c(ctx, k_d, F2(K_d), (float*)real, planes, Nx, Ny, Nk, Nl);
 }
 
@@ -461,14 +514,11 @@ extern "C" int aefft_kernel_export(aefft_ctx* ctx, const float* K_d, float* k_d,
     if (!ctx || !k_d || !K_d || nA <= 0 || nB <= 0 || Nk <= 0 || Nl <= 0 || Nk > Nx || Nl > Ny) return fail(ctx, AEFFT_EINVAL, "aefft_kernel_export: bad argument");
     RET_IF(chk_size(ctx, Nx, Ny));
     const long planes = (long)nA * nB;
-    void* real;
-    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    void *real = nullptr, *part = nullptr;
+    if (pruned_supported(Nk, Nl, Nx, Ny)) RET_IF(ws_get(ctx, WS_PART, sizeof(float) * kgrad_partial_floats(planes, Nx, Ny, Nk, Nl), &part));
+    else RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
     // kfft_inv: C2R then * 1/(Nx*Ny) (fft_backproplib.cu:948), then kernel_invpad
-    RET_IF(do_c2r(ctx, CF2(K_d), (float*)real, planes, Nx, Ny, Nx, Ny, 1.0f / ((float)Nx * (float)Ny)));
-    Bracket br(ctx, KID_SHRINK, (double)planes * Nk * Nl * 8.0);
-    hipError_t e = launch_shrink((const float*)real, k_d, planes, Nx, Ny, Nk, Nl, 1.0f, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "shrink", e);
-    return AEFFT_OK;
+    return do_c2r_shrink(ctx, CF2(K_d), k_d, (float*)real, (float*)part, planes, Nx, Ny, Nk, Nl, 1.0f / ((float)Nx * (float)Ny));
 }
 
 extern "C" int aefft_conv(aefft_ctx* ctx, const float* X_d, const float* C_d, const float* bias_d, float* O_d, int B, int dM, int dD, int Nx, int Ny)
@@ -487,18 +537,16 @@ extern "C" int aefft_gradient(aefft_ctx* ctx, const float* Xin_d, const float* X
         return fail(ctx, AEFFT_EINVAL, "aefft_gradient: bad argument");
     RET_IF(chk_size(ctx, Nx, Ny));
     const long P = bins(Nx, Ny);
-    void *G, *Hp, *E;
-    RET_IF(ws_get(ctx, WS_G, sizeof(float2) * B * dM * P, &G));
-    RET_IF(ws_get(ctx, WS_HP, sizeof(float2) * B * dM * P, &Hp));
-    RET_IF(ws_get(ctx, WS_E, sizeof(float2) * B * dD * P, &E));
-    RET_IF(do_diff_mse(ctx, CF2(Xout_d), CF2(O_d), (float2*)E, nullptr, B, dM, dD, Nx, Ny));
-    return do_gradient(ctx, CF2(Xin_d), (float2*)E, CF2(C_d), CF2(F_d), b_d, (float2*)G, (float2*)Hp, F2(dc_d), F2(df_d), db_d, dp_d, B, dM, dD, Nx, Ny);
+    void* S;
+    RET_IF(ws_get(ctx, WS_S, sizeof(float2) * dD * dD * P, &S));
+    return do_gradient(ctx, CF2(Xin_d), CF2(Xout_d), CF2(O_d), CF2(C_d), CF2(F_d), b_d, (float2*)S, F2(dc_d), F2(df_d), db_d, dp_d, B, dM, dD, Nx, Ny);
 }
 
 extern "C" int aefft_mse(aefft_ctx* ctx, const float* T_d, const float* O_d, float* mse_d, int B, int dM, int dD, int Nx, int Ny)
 {
     if (!ctx || !T_d || !O_d || !mse_d || B <= 0) return fail(ctx, AEFFT_EINVAL, "aefft_mse: bad argument");
-    return do_diff_mse(ctx, CF2(T_d), CF2(O_d), nullptr, mse_d, B, dM, dD, Nx, Ny);
+    HIPCHK(ctx, hipMemsetAsync(mse_d, 0, sizeof(float), ctx->stream));
+    return do_diff_mse(ctx, CF2(T_d), CF2(O_d), nullptr, mse_d, nullptr, B, dM, dD, Nx, Ny);
 }
 
 extern "C" int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, float* p_d, float* C_d, float* F_d,
@@ -511,12 +559,13 @@ extern "C" int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, 
     RET_IF(chk_size(ctx, Nx, Ny));
     const long planes = (long)dM * dD;
     const size_t nk = (size_t)planes * Nk * Nl;
-    void *real, *tmp;
-    RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
+    void *real = nullptr, *tmp, *part = nullptr;
+    if (pruned_supported(Nk, Nl, Nx, Ny)) RET_IF(ws_get(ctx, WS_PART, sizeof(float) * kgrad_partial_floats(planes, Nx, Ny, Nk, Nl), &part));
+    else RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * planes * Nx * Ny, &real));
     RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * 2 * nk, &tmp));
     float* dck = (float*)tmp; float* dfk = dck + nk;
-    RET_IF(do_c2r_shrink(ctx, CF2(dc_d), dck, (float*)real, planes, Nx, Ny, Nk, Nl));
-    RET_IF(do_c2r_shrink(ctx, CF2(df_d), dfk, (float*)real, planes, Nx, Ny, Nk, Nl));
+    RET_IF(do_c2r_shrink(ctx, CF2(dc_d), dck, (float*)real, (float*)part, planes, Nx, Ny, Nk, Nl));
+    RET_IF(do_c2r_shrink(ctx, CF2(df_d), dfk, (float*)real, (float*)part, planes, Nx, Ny, Nk, Nl));
     RET_IF(do_update(ctx, c_d, f_d, b_d, p_d, dck, dfk, db_d, dp_d, Momentum{Dc_d, Df_d, Db_d, Dp_d}, dM, dD, Nk, Nl, del, maxdiff, 0, 1.0f));
     RET_IF(do_pad_r2c(ctx, c_d, F2(C_d), (float*)real, planes, Nx, Ny, Nk, Nl));
     RET_IF(do_pad_r2c(ctx, f_d, F2(F_d), (float*)real, planes, Nx, Ny, Nk, Nl));
@@ -597,8 +646,11 @@ struct Pair {
     float *Dc, *Df, *Db, *Dp;
     float2 *C, *F;
     bool spectra_valid;
-    float2 *X, *H, *O, *U;   // [B][dD][P], [B][dM][P], [B][dD][P], [B][dD][Pin] (U == O when s == 1; X aliases prev H when s == 1)
+    float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
     size_t goff;             // offset (floats) of this pair's segment in the packed gradient buffer
+    float* es;               // [2*dD] DC bins of the error summed over the batch (inside the net scratch)
+    float2 *S, *dc, *df;     // per-pair gradient workspaces (pairs run concurrently on side streams); df == dc + W
+    float* part;             // kgrad partial sums
 };
 
 struct aefft_net {
@@ -608,13 +660,16 @@ struct aefft_net {
     std::vector<void*> allocs;
     float2* A0 = nullptr;      // R2C of the frames when pair 0 does not pool (then X_0 == A0)
     float* grad = nullptr; size_t grad_n = 0;
-    float* mse_pre = nullptr;  // [L]
+    float* scratch = nullptr;  // [mse_pre[L] | mse_post[L] | es of pair 0 (2*dD) | es of pair 1 | ...], zeroed once per step
+    size_t scratch_n = 0;
+    float* mse_pre = nullptr;  // = scratch
+    float* mse_post = nullptr; // = scratch + L
     float* mse_dev = nullptr;  // scratch for bursts
     size_t mse_cap = 0;
     const float* last_frames = nullptr;
     bool have_forward = false, have_grad = false;
     // shared scratch sized for the largest pair
-    float2 *G, *Hp, *E, *dc, *df;
+    bool pruned = true;        // every pair's kernel support has a pruned transform -> no shared FFT workspace in the backward
     float* real;
 };
 
@@ -645,7 +700,8 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     n->ctx = ctx; n->D = d->D; n->Nx = d->Nx; n->Ny = d->Ny; n->L = d->npairs; n->B = d->batch;
     n->pr.resize(n->L);
     int dD = d->D, nx = d->Nx, ny = d->Ny;
-    size_t maxBMP = 0, maxBDP = 0, maxW = 0, maxReal = 0, goff = 0, maxMid = 0, maxDen = 0, maxSmall = 0;
+    size_t maxS = 0, maxBDP = 0, maxW = 0, maxReal = 0, goff = 0, maxMid = 0, maxDen = 0, maxSmall = 0, soff = 2 * (size_t)d->npairs;
+    std::vector<size_t> esoff(d->npairs);
     int rc = AEFFT_OK;
     for (int l = 0; l < n->L && rc == AEFFT_OK; ++l) {
         Pair& q = n->pr[l];
@@ -658,20 +714,25 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
         if (nk < (size_t)q.dM || nk < (size_t)q.dD) { rc = fail(ctx, AEFFT_EINVAL, "aefft_net_create: degenerate kernel"); break; }
         q.goff = goff; goff += 2 * nk + q.dM + q.dD;
-        float** w[] = {&q.c, &q.f, &q.Dc, &q.Df};
-        for (auto pp : w) if ((rc = net_alloc_t(n, pp, nk)) != AEFFT_OK) break;
-        if (rc) break;
+        // c|f, Dc|Df, C|F and dc|df are each ONE allocation so that both kernels of a pair go through one launch
+        if ((rc = net_alloc_t(n, &q.c, 2 * nk)) || (rc = net_alloc_t(n, &q.Dc, 2 * nk))) break;
+        q.f = q.c + nk; q.Df = q.Dc + nk;
         if ((rc = net_alloc_t(n, &q.b, q.dM)) || (rc = net_alloc_t(n, &q.Db, q.dM)) || (rc = net_alloc_t(n, &q.p, q.dD)) || (rc = net_alloc_t(n, &q.Dp, q.dD))) break;
         const size_t W = (size_t)q.dM * q.dD * q.P;
-        if ((rc = net_alloc_t(n, &q.C, W)) || (rc = net_alloc_t(n, &q.F, W))) break;
+        if ((rc = net_alloc_t(n, &q.C, 2 * W))) break;
+        q.F = q.C + W;
         q.spectra_valid = false;
         const size_t BDP = (size_t)n->B * q.dD * q.P, BMP = (size_t)n->B * q.dM * q.P;
         if (q.s == 1 && l > 0) q.X = n->pr[l - 1].H;
         else if ((rc = net_alloc_t(n, &q.X, BDP))) break;
         if ((rc = net_alloc_t(n, &q.H, BMP)) || (rc = net_alloc_t(n, &q.O, BDP))) break;
-        if (q.s == 1) q.U = q.O;
-        else if ((rc = net_alloc_t(n, &q.U, (size_t)n->B * q.dD * bins(nx, ny)))) break;
-        maxBMP = std::max(maxBMP, BMP); maxBDP = std::max(maxBDP, BDP); maxW = std::max(maxW, W);
+        if ((rc = net_alloc_t(n, &q.S, (size_t)q.dD * q.dD * q.P)) || (rc = net_alloc_t(n, &q.dc, 2 * W))) break;
+        q.df = q.dc + W;
+        q.part = nullptr;
+        if (pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny)) { if ((rc = net_alloc_t(n, &q.part, kgrad_partial_floats(2L * q.dM * q.dD, q.Nx, q.Ny, q.Nk, q.Nl)))) break; }
+        else n->pruned = false;
+        maxS = std::max(maxS, (size_t)q.dD * q.dD * q.P); maxBDP = std::max(maxBDP, BDP); maxW = std::max(maxW, W);
+        esoff[l] = soff; soff += 2 * (size_t)q.dD;
         maxReal = std::max(maxReal, (size_t)q.dM * q.dD * q.Nx * q.Ny);
         maxMid = std::max(maxMid, (size_t)q.dM * q.dD * q.Nx * (q.Ny / 2));
         maxDen = std::max(maxDen, 2 * (size_t)q.dM * q.dD * q.dM * q.dD);
@@ -685,10 +746,10 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         if ((rc = ws_get(ctx, WS_MID, sizeof(float2) * maxMid, &dummy)) == AEFFT_OK &&
             (rc = ws_get(ctx, WS_DEN, sizeof(float) * maxDen, &dummy)) == AEFFT_OK &&
             (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->G, maxBMP)) == AEFFT_OK && (rc = net_alloc_t(n, &n->Hp, maxBMP)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->E, maxBDP)) == AEFFT_OK && (rc = net_alloc_t(n, &n->dc, maxW)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->df, maxW)) == AEFFT_OK && (rc = net_alloc_t(n, &n->real, maxReal)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->grad, goff)) == AEFFT_OK && (rc = net_alloc_t(n, &n->mse_pre, (size_t)n->L)) == AEFFT_OK) {
+            (rc = net_alloc_t(n, &n->real, n->pruned ? 64 : maxReal)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->grad, goff)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
+            n->scratch_n = soff; n->mse_pre = n->scratch; n->mse_post = n->scratch + n->L;
+            for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
             n->grad_n = goff;
             if (n->pr[0].s == 1) n->A0 = n->pr[0].X;
         }
@@ -703,6 +764,13 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         e = hipMemsetAsync(q.p, 0, q.dD * 4, ctx->stream); if (e) break;
     }
     if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset weights", e); }
+    if (!ctx->aux[0]) {
+        for (int i = 0; i < aefft_ctx::NAUX; ++i) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    }
     *out = n;
     return aefft_net_reset_momentum(n);
 }
@@ -750,12 +818,19 @@ extern "C" int aefft_net_get_pair(aefft_net* n, int l, float* c_h, float* b_h, f
     return AEFFT_OK;
 }
 
+// kernels -> spectra for both tensors of a pair (StoreLoad_cfreq first pass, fft_backproplib.cu:1150-1152; :1274-1282)
+static int pair_spectra(aefft_net* n, Pair& q)
+{
+    const long planes = (long)q.dM * q.dD;
+    if (pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny)) return do_pad_r2c(n->ctx, q.c, q.C, nullptr, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl);
+    RET_IF(do_pad_r2c(n->ctx, q.c, q.C, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    return do_pad_r2c(n->ctx, q.f, q.F, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl);
+}
+
 static int ensure_spectra(aefft_net* n, Pair& q)
 {
     if (q.spectra_valid) return AEFFT_OK;
-    const long planes = (long)q.dM * q.dD;
-    RET_IF(do_pad_r2c(n->ctx, q.c, q.C, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
-    RET_IF(do_pad_r2c(n->ctx, q.f, q.F, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    RET_IF(pair_spectra(n, q));
     q.spectra_valid = true;
     return AEFFT_OK;
 }
@@ -814,15 +889,12 @@ extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* rec
         if (l > 0 && q.s != 1) RET_IF(do_resize(ctx, n->pr[l - 1].H, q.X, (long)B * q.dD, q.Nxin, q.Nyin, q.Nx, q.Ny));
         RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny));
     }
-    // decoder (:1356-1361): conv then zero-pad up-sampling
-    const float2* Y = n->pr[L - 1].H;
+    // decoder (:1356-1361): conv then zero-pad up-sampling.  The up-sampled tensor is never stored: the next
+    // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
     for (int l = L - 1; l >= 0; --l) {
         Pair& q = n->pr[l];
-        RET_IF(do_conv(ctx, Y, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
-        if (l > 0) {
-            if (q.s != 1) RET_IF(do_resize(ctx, q.O, q.U, (long)B * q.dD, q.Nx, q.Ny, q.Nxin, q.Nyin));
-            Y = q.U;
-        }
+        if (l == L - 1) RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
+        else { const Pair& in = n->pr[l + 1]; RET_IF(do_conv_up(ctx, in.O, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny, in.Nx, in.Ny)); }
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
         Pair& q = n->pr[0];
@@ -863,21 +935,20 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     return do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y));
 }
 
-// one loop-body iteration on pair q given X (=T) and the current O; writes new H, O
-static int pair_grad(aefft_net* n, Pair& q, float* mse_slot)
+// gradient half of one loop-body iteration on pair q: needs X (= T, autoencoder.cpp:194) and the current O.
+static int pair_grad(aefft_net* n, Pair& q)
 {
     aefft_ctx* ctx = n->ctx;
-    // E = O - T (T = the pair's own input, autoencoder.cpp:194) fused with the pre-update MSE
-    RET_IF(do_diff_mse(ctx, q.X, q.O, n->E, mse_slot, n->B, q.dM, q.dD, q.Nx, q.Ny));
     float* g = n->grad + q.goff;
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
-    RET_IF(do_gradient(ctx, q.X, n->E, q.C, q.F, q.b, n->G, n->Hp, n->dc, n->df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    RET_IF(do_gradient(ctx, q.X, q.X, q.O, q.C, q.F, q.b, q.S, q.dc, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.Nx, q.Ny));
     const long planes = (long)q.dM * q.dD;
-    RET_IF(do_c2r_shrink(ctx, n->dc, g, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
-    RET_IF(do_c2r_shrink(ctx, n->df, g + nk, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
-    return AEFFT_OK;
+    if (q.part) return do_c2r_shrink(ctx, q.dc, g, nullptr, q.part, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl);   // dc|df -> dck|dfk, one launch
+    RET_IF(do_c2r_shrink(ctx, q.dc, g, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    return do_c2r_shrink(ctx, q.df, g + nk, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl);
 }
 
+// update half: weights, new spectra, re-forward of the pair alone, post-update MSE accumulated into *mse_slot (pre-zeroed)
 static int pair_apply(aefft_net* n, Pair& q, float del, int maxdiff, int sym, float gscale, float* mse_slot)
 {
     aefft_ctx* ctx = n->ctx;
@@ -885,13 +956,11 @@ static int pair_apply(aefft_net* n, Pair& q, float del, int maxdiff, int sym, fl
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
     RET_IF(do_update(ctx, q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
                      q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale));
-    const long planes = (long)q.dM * q.dD;
-    RET_IF(do_pad_r2c(ctx, q.c, q.C, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
-    RET_IF(do_pad_r2c(ctx, q.f, q.F, n->real, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    RET_IF(pair_spectra(n, q));
     // re-forward of this pair alone (fft_backproplib.cu:1460-1461) and its MSE (:1463)
     RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, n->B, q.dM, q.dD, q.Nx, q.Ny));
     RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, n->B, q.dD, q.dM, q.Nx, q.Ny));
-    if (mse_slot) RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, mse_slot, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    if (mse_slot) RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, mse_slot, nullptr, n->B, q.dM, q.dD, q.Nx, q.Ny));
     return AEFFT_OK;
 }
 
@@ -913,11 +982,11 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     HIPCHK(ctx, hipMemsetAsync(q.Db, 0, q.dM * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(q.Dp, 0, q.dD * 4, ctx->stream));
     const float del = 0.1f * del0;                      // :1445
-    if (n_iter == 0) RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_dev, n->B, q.dM, q.dD, q.Nx, q.Ny));
+    HIPCHK(ctx, hipMemsetAsync(n->mse_dev, 0, sizeof(float) * (n_iter + 1), ctx->stream));
+    RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_dev, nullptr, n->B, q.dM, q.dD, q.Nx, q.Ny));     // :1440
     for (int it = 0; it < n_iter; ++it) {
-        // the pre-update MSE of iteration `it` is the reference's print of iteration it-1 (or the initial one, :1440)
-        RET_IF(pair_grad(n, q, n->mse_dev + it));
-        RET_IF(pair_apply(n, q, del, maxdiff, sym, 1.0f, it == n_iter - 1 ? n->mse_dev + n_iter : nullptr));
+        RET_IF(pair_grad(n, q));
+        RET_IF(pair_apply(n, q, del, maxdiff, sym, 1.0f, n->mse_dev + it + 1));
     }
     n->have_grad = false;
     if (mse_h) {
@@ -927,11 +996,40 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     return AEFFT_OK;
 }
 
+// Independent per-pair work is spread over side streams: fork() makes every side stream wait for
+// what is already enqueued on the caller's stream; join() makes the caller's stream wait for them.
+static int fork_streams(aefft_ctx* ctx)
+{
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    return AEFFT_OK;
+}
+static int join_streams(aefft_ctx* ctx)
+{
+    ctx->cur = ctx->stream;
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
+    }
+    return AEFFT_OK;
+}
+static bool use_side_streams(const aefft_net* n) { return n->pruned && n->L > 1 && n->ctx->aux[0] != nullptr; }
+
 extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* recon_d)
 {
     if (!n) return AEFFT_EINVAL;
+    aefft_ctx* ctx = n->ctx;
     RET_IF(aefft_net_forward(n, frames_d, recon_d));
-    for (int l = 0; l < n->L; ++l) RET_IF(pair_grad(n, n->pr[l], n->mse_pre + l));
+    HIPCHK(ctx, hipMemsetAsync(n->scratch, 0, sizeof(float) * n->scratch_n, ctx->stream));   // all MSE slots + es, once per step
+    const bool side = use_side_streams(n);
+    if (side) RET_IF(fork_streams(ctx));
+    int rc = AEFFT_OK;
+    for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {     // small (launch-bound) pairs first, the big ones fill in
+        if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
+        rc = pair_grad(n, n->pr[l]);
+    }
+    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; }
+    RET_IF(rc);
     n->have_grad = true;
     return AEFFT_OK;
 }
@@ -947,9 +1045,19 @@ extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloat
 extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int sym, float grad_scale, float* mse_d)
 {
     if (!n) return AEFFT_EINVAL;
-    if (!n->have_grad) return fail(n->ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
+    aefft_ctx* ctx = n->ctx;
+    if (!n->have_grad) return fail(ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
     const float del = 0.1f * del0;
-    for (int l = 0; l < n->L; ++l) RET_IF(pair_apply(n, n->pr[l], del, maxdiff, sym, grad_scale, mse_d ? mse_d + l : nullptr));
+    const bool side = use_side_streams(n) && !maxdiff;        // the multiobjective path shares context workspaces
+    if (side) RET_IF(fork_streams(ctx));
+    int rc = AEFFT_OK;
+    for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {
+        if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
+        rc = pair_apply(n, n->pr[l], del, maxdiff, sym, grad_scale, n->mse_post + l);
+    }
+    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; }
+    RET_IF(rc);
+    if (mse_d) HIPCHK(ctx, hipMemcpyAsync(mse_d, n->mse_post, sizeof(float) * n->L, hipMemcpyDeviceToDevice, ctx->stream));
     n->have_grad = false;
     return AEFFT_OK;
 }

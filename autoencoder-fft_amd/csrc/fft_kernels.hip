@@ -43,6 +43,13 @@ hipError_t upload_twiddles(hipStream_t st)
     return hipStreamSynchronize(st);
 }
 
+const float2* twiddle_table()
+{
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tw)) != hipSuccess) return nullptr;
+    return static_cast<const float2*>(p);
+}
+
 bool fft_size_supported(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 0; }
 
 // ------------------------------------------------------------------------------------------

@@ -30,25 +30,41 @@ size_t fft_mid_elems(long planes, int Nx, int Wc);   // complex elements needed 
 // both halves of gradient_k_io (fft.cu:395).  Strides are in complex elements.
 struct Contract {
     const float2* A; long a_r, a_k;     // A[r][k] plane base = A + r*a_r + k*a_k
+    const float2* A2;                   // optional: the A operand is (A - A2), same strides (E = O - T fused, fft.cu:417-424)
     const float2* B; long b_k, b_c;     // B[k][c] plane base = B + k*b_k + c*b_c
     float2* Out;     long o_r, o_c;     // Out[r][c] plane base
     int R, C, K;                        // rows, cols, contraction length
-    long P;                             // bins per plane
+    long P;                             // bins per (A / Out) plane
     bool conjA, conjB;
     float preDivB;                      // !=0: B elements are divided by this BEFORE the product (conv_k: in/dM, fft.cu:176-177)
     float postDiv;                      // !=0: the sum is divided by this (gradient_k_io: /Norm, fft.cu:440-441)
     const float* bias; float biasScale; // Re(Out[r][c][0]) += bias[r]*biasScale; null = none
     bool biasAfterFirst;                // true: added right after the k==0 term (fft.cu:183-184); false: after the sum (fft.cu:454)
+    // Virtual spectral up-sampling of the B operand (fft.cu:117-152 fused into the consumer): B planes
+    // are [upNxs][upNys/2+1] spectra that are zero-padded on the fly to the [upNx][upNy/2+1] grid of A/Out.
+    // Destination bins outside the padded support only receive the bias term (everything else is 0).
+    int upNx, upNy, upNxs, upNys;       // upNx == 0: no remap
 };
+struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
+hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 hipError_t launch_contract(const Contract& q, hipStream_t st);
 
 hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st);
 // E = O - T and MSE (fft.cu:480-498): *mse_acc += scale * sum_bins |T-O|^2/n_bin.
 hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullable*/, float* mse_acc /*1 float, pre-zeroed, nullable*/,
-                           int B, int ch, int Nx, int Ny, float scale, hipStream_t st);
-// db[m] = mean_b Re G_b[m](0) * norm/Norm ; dp[d] = mean_b Re E_b[d](0) * norm/Norm  (fft.cu:463-473)
-hipError_t launch_bias_grad(const float2* G, const float2* E, float* db, float* dp, int B, int dM, int dD, long P,
-                            float norm, float Norm, hipStream_t st);
+                           float* es /*[2*ch] floats, pre-zeroed, nullable: sum_b E_b[d](0,0)*/, int B, int ch, int Nx, int Ny, float scale, hipStream_t st);
+// db, dp and the DC-bin bias term of df from es[d] = sum_b (O_b[d] - T_b[d])(0,0)  (fft.cu:448-455,463-473)
+hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
+                            int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st);
+
+// ---- pruned_kernels.hip ----------------------------------------------------------------
+// Kernel-support-pruned transforms: only Nk x Nl taps are non-zero going forward / needed coming back,
+// so pad+R2C and C2R+shrink become direct DFT evaluations (fft.cu:1219-1226 and :1274-1282 fused).
+bool pruned_supported(int Nk, int Nl, int Nx, int Ny);
+hipError_t launch_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);
+hipError_t launch_kgrad(const float2* D, float* g, float* part /*workspace: kgrad_partial_floats()*/, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, float scale, hipStream_t st);
+size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
+const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()
 
 // ---- update_kernels.hip ----------------------------------------------------------------
 hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);   // fft.cu:570 (zero-fills)

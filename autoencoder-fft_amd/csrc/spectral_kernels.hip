@@ -16,6 +16,8 @@
 // Bins are the fastest dimension everywhere, so a wave reads 64 x 16 B = 1 KiB contiguous per
 // load instruction; each thread owns two bins (one float4) and a TR x TC register tile of outputs.
 #include "internal.h"
+#include <algorithm>
+#include <type_traits>
 
 namespace aefft {
 
@@ -25,104 +27,203 @@ __device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b)
     acc.y += a.x * b.y + a.y * b.x;
 }
 
-template <int TR, int TC, bool CA, bool CB>
-__global__ __launch_bounds__(256) void contract_kernel(const Contract q)
+// Thread layout: threadIdx.x = 64 consecutive bin groups (VEC bins each: one float2 or float4 per
+// load, so a wave reads 512 B / 1 KiB contiguous), threadIdx.y = up to 4 row tiles that share
+// the B operand through L1.  Each thread owns a TR x TC register tile of outputs.
+template <int VEC, int TR, int TC>
+__device__ __forceinline__ void contract_body(const Contract& q, int zblk)
 {
-    const long pair = (long)blockIdx.x * 256 + threadIdx.x;      // index of the float4 (two bins)
-    if (pair * 2 >= q.P) return;
-    const int r0 = blockIdx.y * TR, c0 = blockIdx.z * TC;
-    const float4* A4 = reinterpret_cast<const float4*>(q.A);
-    const float4* B4 = reinterpret_cast<const float4*>(q.B);
+    using V = typename std::conditional<VEC == 2, float4, float2>::type;
+    const long grp = (long)blockIdx.x * 64 + threadIdx.x;       // index of the bin group
+    if (grp * VEC >= q.P) return;
+    const int r0 = (blockIdx.y * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
+    if (r0 >= q.R || c0 >= q.C) return;
+    const V* Ap = reinterpret_cast<const V*>(q.A);
+    const V* A2p = reinterpret_cast<const V*>(q.A2);
+    const V* Bp = reinterpret_cast<const V*>(q.B);
+    long bgrp = grp;                    // bin group inside a B plane
+    bool live = true;                   // false: destination bin has no source under the zero-pad remap
+    if (VEC == 1 && q.upNx) {
+        const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
+        const int i = (int)(grp / Nyr), j = (int)(grp - (long)i * Nyr);
+        int si = -1, sj = -1;
+        if (i < q.upNxs / 2) si = i;
+        else if (i > q.upNx - q.upNxs / 2) si = i - q.upNx + q.upNxs;
+        else if (i == q.upNx / 2) si = q.upNxs / 2;
+        if (j < Nyrs - 1) sj = j;
+        else if (j == Nyr - 1) sj = Nyrs - 1;
+        live = (si >= 0 && sj >= 0);
+        bgrp = (long)si * Nyrs + sj;
+    }
     long aoff[TR], boff[TC];
     int rr[TR];
 #pragma unroll
-    for (int i = 0; i < TR; ++i) { rr[i] = (r0 + i < q.R) ? r0 + i : q.R - 1; aoff[i] = (rr[i] * q.a_r) / 2 + pair; }
+    for (int i = 0; i < TR; ++i) { rr[i] = (r0 + i < q.R) ? r0 + i : q.R - 1; aoff[i] = (rr[i] * q.a_r) / VEC + grp; }
 #pragma unroll
-    for (int j = 0; j < TC; ++j) { const int cc = (c0 + j < q.C) ? c0 + j : q.C - 1; boff[j] = (cc * q.b_c) / 2 + pair; }
-    const long a_k2 = q.a_k / 2, b_k2 = q.b_k / 2;
+    for (int j = 0; j < TC; ++j) { const int cc = (c0 + j < q.C) ? c0 + j : q.C - 1; boff[j] = (cc * q.b_c) / VEC + bgrp; }
+    const long a_kv = q.a_k / VEC, b_kv = q.b_k / VEC;
+    const float sa = q.conjA ? -1.f : 1.f, sb = q.conjB ? -1.f : 1.f;
+    const float binv = q.preDivB;
 
-    float2 acc0[TR][TC], acc1[TR][TC];
+    float2 acc[VEC][TR][TC];
 #pragma unroll
-    for (int i = 0; i < TR; ++i)
-#pragma unroll
-        for (int j = 0; j < TC; ++j) acc0[i][j] = acc1[i][j] = make_float2(0.f, 0.f);
-
-    const bool dc_thread = (pair == 0);
-    for (int k = 0; k < q.K; ++k) {
-        float4 a[TR], b[TC];
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-            a[i] = A4[aoff[i] + k * a_k2];
-            if (CA) { a[i].y = -a[i].y; a[i].w = -a[i].w; }
-        }
-#pragma unroll
-        for (int j = 0; j < TC; ++j) {
-            b[j] = B4[boff[j] + k * b_k2];
-            if (q.preDivB != 0.f) { b[j].x /= q.preDivB; b[j].y /= q.preDivB; b[j].z /= q.preDivB; b[j].w /= q.preDivB; }
-            if (CB) { b[j].y = -b[j].y; b[j].w = -b[j].w; }
-        }
+    for (int v = 0; v < VEC; ++v)
 #pragma unroll
         for (int i = 0; i < TR; ++i)
 #pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                cfma(acc0[i][j], make_float2(a[i].x, a[i].y), make_float2(b[j].x, b[j].y));
-                cfma(acc1[i][j], make_float2(a[i].z, a[i].w), make_float2(b[j].z, b[j].w));
+            for (int j = 0; j < TC; ++j) acc[v][i][j] = make_float2(0.f, 0.f);
+
+    const bool dc_thread = (grp == 0);
+    if (live) {
+#pragma unroll 2
+        for (int k = 0; k < q.K; ++k) {
+            V a[TR], b[TC];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) a[i] = Ap[aoff[i] + k * a_kv];
+            if (A2p) {
+#pragma unroll
+                for (int i = 0; i < TR; ++i) {
+                    const V a2 = A2p[aoff[i] + k * a_kv];
+                    float* af = reinterpret_cast<float*>(&a[i]);
+                    const float* a2f = reinterpret_cast<const float*>(&a2);
+#pragma unroll
+                    for (int e = 0; e < 2 * VEC; ++e) af[e] -= a2f[e];
+                }
             }
-        if (k == 0 && q.bias && q.biasAfterFirst && dc_thread) {
 #pragma unroll
-            for (int i = 0; i < TR; ++i)
+            for (int j = 0; j < TC; ++j) b[j] = Bp[boff[j] + k * b_kv];
 #pragma unroll
-                for (int j = 0; j < TC; ++j) acc0[i][j].x += q.bias[rr[i]] * q.biasScale;
+            for (int j = 0; j < TC; ++j) {
+                float* bf = reinterpret_cast<float*>(&b[j]);
+                if (binv != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 2 * VEC; ++e) bf[e] = bf[e] / binv;
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) bf[2 * v + 1] *= sb;
+            }
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                float* af = reinterpret_cast<float*>(&a[i]);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) af[2 * v + 1] *= sa;
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) {
+                        const float* af = reinterpret_cast<const float*>(&a[i]);
+                        const float* bf = reinterpret_cast<const float*>(&b[j]);
+                        cfma(acc[v][i][j], make_float2(af[2 * v], af[2 * v + 1]), make_float2(bf[2 * v], bf[2 * v + 1]));
+                    }
+            if (k == 0 && q.bias && q.biasAfterFirst && dc_thread) {
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) acc[0][i][j].x += q.bias[rr[i]] * q.biasScale;
+            }
         }
     }
-    float4* O4 = reinterpret_cast<float4*>(q.Out);
+    V* Op = reinterpret_cast<V*>(q.Out);
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
             if (r0 + i >= q.R || c0 + j >= q.C) continue;
-            float2 v0 = acc0[i][j], v1 = acc1[i][j];
-            if (q.bias && !q.biasAfterFirst && dc_thread) v0.x += q.bias[rr[i]] * q.biasScale;
-            if (q.postDiv != 0.f) { v0.x /= q.postDiv; v0.y /= q.postDiv; v1.x /= q.postDiv; v1.y /= q.postDiv; }
-            O4[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / 2 + pair] = make_float4(v0.x, v0.y, v1.x, v1.y);
+            V o;
+            float* of = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float2 val = acc[v][i][j];
+                if (v == 0 && q.bias && !q.biasAfterFirst && dc_thread) val.x += q.bias[rr[i]] * q.biasScale;
+                if (q.postDiv != 0.f) { val.x /= q.postDiv; val.y /= q.postDiv; }
+                of[2 * v] = val.x; of[2 * v + 1] = val.y;
+            }
+            Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
         }
 }
 
-template <int TR, int TC> static hipError_t contract_tile(const Contract& q, hipStream_t st)
+template <int VEC, int TR, int TC>
+__global__ __launch_bounds__(256) void contract_kernel(const Contract2 qq, int z0)
 {
-    const long pairs = q.P / 2;
-    dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)((q.R + TR - 1) / TR), (unsigned)((q.C + TC - 1) / TC));
-    if (q.conjA && q.conjB) contract_kernel<TR, TC, true, true><<<grid, 256, 0, st>>>(q);
-    else if (q.conjA) contract_kernel<TR, TC, true, false><<<grid, 256, 0, st>>>(q);
-    else if (q.conjB) contract_kernel<TR, TC, false, true><<<grid, 256, 0, st>>>(q);
-    else contract_kernel<TR, TC, false, false><<<grid, 256, 0, st>>>(q);
+    // grid.z = [0, z0) -> problem 0, [z0, ...) -> problem 1
+    if ((int)blockIdx.z < z0) contract_body<VEC, TR, TC>(qq.q[0], blockIdx.z);
+    else contract_body<VEC, TR, TC>(qq.q[1], blockIdx.z - z0);
+}
+
+template <int VEC, int TR, int TC> static hipError_t contract_tile(const Contract2& qq, hipStream_t st)
+{
+    long gx = 0; int gy = 0, by = 1, z[2] = {0, 0};
+    for (int p = 0; p < qq.n; ++p) {
+        const Contract& q = qq.q[p];
+        const long groups = (q.P + VEC - 1) / VEC;
+        const int rtiles = (q.R + TR - 1) / TR;
+        gx = std::max(gx, (groups + 63) / 64);
+        by = std::max(by, rtiles < 4 ? rtiles : 4);
+        z[p] = (q.C + TC - 1) / TC;
+    }
+    for (int p = 0; p < qq.n; ++p) gy = std::max(gy, ((qq.q[p].R + TR - 1) / TR + by - 1) / by);
+    contract_kernel<VEC, TR, TC><<<dim3((unsigned)gx, gy, z[0] + z[1]), dim3(64, by), 0, st>>>(qq, z[0]);
     return hipGetLastError();
+}
+
+static bool contract_even(const Contract& q)
+{
+    return !((q.P & 1) || (q.a_r & 1) || (q.a_k & 1) || (q.b_k & 1) || (q.b_c & 1) || (q.o_r & 1) || (q.o_c & 1)) && !q.upNx;
+}
+
+hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
+{
+    if (qq.n < 1 || qq.n > 2) return hipErrorInvalidValue;
+    bool even = true;
+    int Rmin = 1 << 30, Cmin = 1 << 30;
+    for (int p = 0; p < qq.n; ++p) {
+        const Contract& q = qq.q[p];
+        if (q.R <= 0 || q.C <= 0 || q.K <= 0 || q.P <= 0) return hipErrorInvalidValue;
+        even = even && contract_even(q);          // the float4 path needs 16-byte aligned plane offsets and no remap
+        Rmin = std::min(Rmin, q.R); Cmin = std::min(Cmin, q.C);
+    }
+    // start from the largest register tile the shapes allow and shrink until the launch has enough waves
+    int tr = Rmin >= 4 ? 4 : (Rmin >= 2 ? 2 : 1), tc = Cmin >= 4 ? 4 : (Cmin >= 2 ? 2 : 1), vec = even ? 2 : 1;
+    auto waves = [&](int v, int r, int c) {
+        long w = 0;
+        for (int p = 0; p < qq.n; ++p) { const Contract& q = qq.q[p]; w += ((q.P + 64L * v - 1) / (64L * v)) * ((q.R + r - 1) / r) * ((q.C + c - 1) / c); }
+        return w;
+    };
+    const long want = 2048;
+    if (waves(vec, tr, tc) < want && vec == 2) vec = 1;
+    if (waves(vec, tr, tc) < want && tr == 4) tr = 2;
+#define AEFFT_CT(V, R_, C_) if (vec == V && tr == R_ && tc == C_) return contract_tile<V, R_, C_>(qq, st);
+    AEFFT_CT(2, 4, 4) AEFFT_CT(2, 4, 2) AEFFT_CT(2, 2, 4) AEFFT_CT(2, 2, 2) AEFFT_CT(2, 4, 1) AEFFT_CT(2, 1, 4) AEFFT_CT(2, 2, 1) AEFFT_CT(2, 1, 2) AEFFT_CT(2, 1, 1)
+    AEFFT_CT(1, 4, 4) AEFFT_CT(1, 4, 2) AEFFT_CT(1, 2, 4) AEFFT_CT(1, 2, 2) AEFFT_CT(1, 4, 1) AEFFT_CT(1, 1, 4) AEFFT_CT(1, 2, 1) AEFFT_CT(1, 1, 2) AEFFT_CT(1, 1, 1)
+#undef AEFFT_CT
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_contract(const Contract& q, hipStream_t st)
 {
-    // every plane offset must keep float4 alignment: P and all strides even (P = Nx*(Ny/2+1), Nx even)
-    if ((q.P & 1) || (q.a_r & 1) || (q.a_k & 1) || (q.b_k & 1) || (q.b_c & 1) || (q.o_r & 1) || (q.o_c & 1)) return hipErrorInvalidValue;
-    if (q.R <= 0 || q.C <= 0 || q.K <= 0) return hipErrorInvalidValue;
-    if (q.C == 1) return contract_tile<4, 1>(q, st);
-    if (q.R == 1) return contract_tile<1, 4>(q, st);
-    if (q.C < 4) return contract_tile<4, 2>(q, st);
-    return contract_tile<4, 4>(q, st);
+    Contract2 qq{};
+    qq.q[0] = q; qq.n = 1;
+    return launch_contract2(qq, st);
 }
 
 // ------------------------------------------------------------------------------------------
 // spectral pooling (fft_backproplib.cu:87-157).  Destination fully written (zeros where the
 // reference relies on its cudaMemset, :990).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resize_kernel(const float2* __restrict__ in, float2* __restrict__ out, long planes,
+template <typename I>   // 32-bit indexing whenever the tensors allow it: 64-bit div/mod costs hundreds of cycles per element
+__global__ __launch_bounds__(256) void resize_kernel(const float2* __restrict__ in, float2* __restrict__ out, I planes,
                                                      int Nx, int Ny, int Nxs, int Nys)
 {
     const int Nyr = Ny / 2 + 1, Nyrs = Nys / 2 + 1;
-    const long total = planes * Nxs * (long)Nyrs;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long d = idx / ((long)Nxs * Nyrs);
-        const int rem = (int)(idx - d * (long)Nxs * Nyrs);
-        const int i = rem / Nyrs, j = rem % Nyrs;
+    const I psz = (I)Nxs * Nyrs;
+    const I total = planes * psz;
+    for (I idx = (I)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (I)gridDim.x * 256) {
+        const I d = idx / psz;
+        const int rem = (int)(idx - d * psz);
+        const int i = rem / Nyrs, j = rem - i * Nyrs;
         int si = -1, sj = -1;
         if (Nxs <= Nx) {
             si = (i < Nxs / 2) ? i : (i == Nxs / 2 ? Nx / 2 : i + Nx - Nxs);
@@ -135,7 +236,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float2* __restrict__ 
             else if (j == Nyrs - 1) sj = Nyr - 1;
         }
         float2 v = make_float2(0.f, 0.f);
-        if (si >= 0 && sj >= 0) v = in[(d * Nx + si) * (long)Nyr + sj];
+        if (si >= 0 && sj >= 0) v = in[(d * Nx + si) * (I)Nyr + sj];
         out[idx] = v;
     }
 }
@@ -143,10 +244,14 @@ __global__ __launch_bounds__(256) void resize_kernel(const float2* __restrict__ 
 hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st)
 {
     const long total = planes * Nxs * (long)(Nys / 2 + 1);
+    const long total_in = planes * Nx * (long)(Ny / 2 + 1);
     if (total <= 0) return hipSuccess;
     long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    resize_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(in, out, planes, Nx, Ny, Nxs, Nys);
+    if (blocks > 4096) blocks = 4096;
+    if (total < (1L << 31) && total_in < (1L << 31))
+        resize_kernel<unsigned><<<dim3((unsigned)blocks), 256, 0, st>>>(in, out, (unsigned)planes, Nx, Ny, Nxs, Nys);
+    else
+        resize_kernel<long><<<dim3((unsigned)blocks), 256, 0, st>>>(in, out, planes, Nx, Ny, Nxs, Nys);
     return hipGetLastError();
 }
 
@@ -155,19 +260,30 @@ hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int
 //   mse = sum_bins |T-O|^2 / n_bin / (2*dM*Nx*Ny),  n_bin = dD*Nx*Ny, halved for columns 0<j<Nyr-1.
 // For a batch the mean over frames is accumulated: *mse_acc += partial * scale.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void diff_mse_kernel(const float2* __restrict__ T, const float2* __restrict__ O,
-                                                       float2* __restrict__ E, float* __restrict__ mse_acc, long total,
-                                                       int Nyr, float nfull, float scale)
+// Two bins per thread (P is even, so a float4 never straddles a plane); at most 256 blocks so the
+// single-address atomics stay cheap.  es[d] += E_b[d](0,0) collects the DC bins of the error for
+// the bias gradients (fft_backproplib.cu:432,471).
+template <typename I>
+__global__ __launch_bounds__(256) void diff_mse_kernel(const float4* __restrict__ T, const float4* __restrict__ O,
+                                                       float4* __restrict__ E, float* __restrict__ mse_acc,
+                                                       float* __restrict__ es, I npairs, I P, int ch, int Nyr,
+                                                       float nfull, float scale)
 {
     float part = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const float2 t = T[idx], o = O[idx];
-        const float dx = o.x - t.x, dy = o.y - t.y;
-        if (E) E[idx] = make_float2(dx, dy);
-        const int j = (int)(idx % Nyr);
-        float n = nfull;
-        if (j > 0 && j < Nyr - 1) n /= 2;
-        part += (dx * dx + dy * dy) / n;
+    const I hp = P / 2;                                  // float4 pairs per plane
+    for (I idx = (I)blockIdx.x * 256 + threadIdx.x; idx < npairs; idx += (I)gridDim.x * 256) {
+        const float4 t = T[idx], o = O[idx];
+        const float4 e = make_float4(o.x - t.x, o.y - t.y, o.z - t.z, o.w - t.w);
+        if (E) E[idx] = e;
+        const I plane = idx / hp;
+        const unsigned bin = (unsigned)(idx - plane * hp) * 2u;
+        if (es && bin == 0) {
+            const int d = (int)(plane % (I)ch);
+            atomicAdd(&es[2 * d], e.x); atomicAdd(&es[2 * d + 1], e.y);
+        }
+        const unsigned j0 = bin % (unsigned)Nyr, j1 = (j0 + 1 == (unsigned)Nyr) ? 0u : j0 + 1;
+        const float n0 = (j0 > 0 && j0 < (unsigned)Nyr - 1) ? nfull / 2 : nfull, n1 = (j1 > 0 && j1 < (unsigned)Nyr - 1) ? nfull / 2 : nfull;
+        part += (e.x * e.x + e.y * e.y) / n0 + (e.z * e.z + e.w * e.w) / n1;
     }
     if (!mse_acc) return;
 #pragma unroll
@@ -178,39 +294,79 @@ __global__ __launch_bounds__(256) void diff_mse_kernel(const float2* __restrict_
     if (threadIdx.x == 0) atomicAdd(mse_acc, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale);
 }
 
-hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* mse_acc, int B, int ch, int Nx, int Ny, float scale, hipStream_t st)
+hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* mse_acc, float* es, int B, int ch, int Nx, int Ny,
+                           float scale, hipStream_t st)
 {
     const int Nyr = Ny / 2 + 1;
-    const long total = (long)B * ch * Nx * Nyr;
-    if (total <= 0) return hipSuccess;
-    long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    diff_mse_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(T, O, E, mse_acc, total, Nyr, (float)ch * Nx * Ny, scale);
+    const long P = (long)Nx * Nyr;
+    const long npairs = (long)B * ch * P / 2;
+    if (npairs <= 0) return hipSuccess;
+    if (P & 1) return hipErrorInvalidValue;
+    long blocks = (npairs + 1023) / 1024;                // >= 4 float4 per thread, at most 512 single-address atomics
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    const float4 *T4 = reinterpret_cast<const float4*>(T), *O4 = reinterpret_cast<const float4*>(O);
+    float4* E4 = reinterpret_cast<float4*>(E);
+    if (npairs < (1L << 30))
+        diff_mse_kernel<unsigned><<<dim3((unsigned)blocks), 256, 0, st>>>(T4, O4, E4, mse_acc, es, (unsigned)npairs, (unsigned)P, ch, Nyr, (float)ch * Nx * Ny, scale);
+    else
+        diff_mse_kernel<long><<<dim3((unsigned)blocks), 256, 0, st>>>(T4, O4, E4, mse_acc, es, npairs, P, ch, Nyr, (float)ch * Nx * Ny, scale);
     return hipGetLastError();
 }
 
-// db[m] = (1/B) sum_b Re G_b[m](0) * norm / Norm ; dp[d] = (1/B) sum_b Re E_b[d](0) * norm / Norm
-__global__ void bias_grad_kernel(const float2* __restrict__ G, const float2* __restrict__ E, float* __restrict__ db,
-                                 float* __restrict__ dp, int B, int dM, int dD, long P, float norm, float Norm)
+// DC-bin terms of gradient_k_io.  es[d] = sum_b (O_b[d](0,0) - T_b[d](0,0)) is rebuilt per workgroup in LDS, then
+//   db[m]       = Re( sum_d1 es[d1] * conj(F[d1][m](0,0)) ) * norm / (Norm*B)      (fft_backproplib.cu:432,465)
+//   dp[d]       = Re es[d] * norm / (Norm*B)                                       (:471)
+//   df[d][m](0,0) += es[d] * b[m]*norm / (Norm*B)    -- the b0 term of :448-455 (H' bias at DC)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict__ O, const float2* __restrict__ T,
+                                                        const float2* __restrict__ F, const float* __restrict__ b,
+                                                        float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < dM) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += G[((long)b * dM + i) * P].x * norm / Norm;
-        db[i] = s / (float)B;
-    } else if (i < dM + dD) {
-        const int d = i - dM;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += E[((long)b * dD + d) * P].x * norm / Norm;
-        dp[d] = s / (float)B;
+    extern __shared__ float2 es[];
+    for (int d = threadIdx.x; d < dD; d += 256) {
+        float2 s = make_float2(0.f, 0.f);
+        for (int bb = 0; bb < B; ++bb) {
+            const long q = ((long)bb * dD + d) * P;
+            const float2 o = O[q], t = T[q];
+            s.x += o.x - t.x; s.y += o.y - t.y;
+        }
+        es[d] = s;
     }
+    __syncthreads();
+    const float den = Norm * (float)B;
+    if ((int)blockIdx.x < fix_blocks) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        if (t < dD * dM) {
+            const int d = t / dM, m = t - d * dM;
+            const float2 e = es[d];
+            const float bb = b[m] * norm;
+            float2* p = df + ((long)d * dM + m) * P;
+            float2 v = *p;
+            v.x += e.x * bb / den; v.y += e.y * bb / den;
+            *p = v;
+        }
+        if (t < dD) dp[t] = es[t].x * norm / den;
+        return;
+    }
+    // db: one wave per output map m, lanes over d1
+    const int m = ((int)blockIdx.x - fix_blocks) * 4 + (threadIdx.x >> 6);
+    if (m >= dM) return;
+    float s = 0.f;
+    for (int d1 = threadIdx.x & 63; d1 < dD; d1 += 64) {
+        const float2 e = es[d1], f = F[((long)d1 * dM + m) * P];
+        s += e.x * f.x + e.y * f.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) db[m] = s * norm / den;
 }
 
-hipError_t launch_bias_grad(const float2* G, const float2* E, float* db, float* dp, int B, int dM, int dD, long P,
-                            float norm, float Norm, hipStream_t st)
+hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
+                            int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st)
 {
-    const int n = dM + dD;
-    bias_grad_kernel<<<dim3((n + 63) / 64), 64, 0, st>>>(G, E, db, dp, B, dM, dD, P, norm, Norm);
+    const int fix_blocks = (dM * dD + 255) / 256;
+    bias_grad_kernel<<<dim3(fix_blocks + (dM + 3) / 4), 256, sizeof(float2) * dD, st>>>(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks);
     return hipGetLastError();
 }
 

@@ -18,14 +18,16 @@ __device__ __forceinline__ int row_tap(int i, int Nk, int Nx)
 }
 
 // memset + pad_k in one pass: every element of the padded plane is written.
-__global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ ck, float* __restrict__ cpad, long planes,
+template <typename I>
+__global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ ck, float* __restrict__ cpad, I planes,
                                                   int Nx, int Ny, int Nk, int Nl)
 {
-    const long total = planes * Nx * (long)Ny;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long pl = idx / ((long)Nx * Ny);
-        const int rem = (int)(idx - pl * (long)Nx * Ny);
-        const int i = rem / Ny, j = rem % Ny;
+    const I psz = (I)Nx * Ny;
+    const I total = planes * psz;
+    for (I idx = (I)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (I)gridDim.x * 256) {
+        const I pl = idx / psz;
+        const int rem = (int)(idx - pl * psz);
+        const int i = rem / Ny, j = rem - i * Ny;
         const int k = row_tap(i, Nk, Nx), l = row_tap(j, Nl, Ny);
         cpad[idx] = (k >= 0 && l >= 0) ? ck[(pl * Nk + k) * Nl + l] : 0.f;
     }
@@ -37,7 +39,8 @@ hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny,
     const long total = planes * Nx * (long)Ny;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    pad_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(ck, cpad, planes, Nx, Ny, Nk, Nl);
+    if (total < (1L << 31)) pad_kernel<unsigned><<<dim3((unsigned)blocks), 256, 0, st>>>(ck, cpad, (unsigned)planes, Nx, Ny, Nk, Nl);
+    else pad_kernel<long><<<dim3((unsigned)blocks), 256, 0, st>>>(ck, cpad, planes, Nx, Ny, Nk, Nl);
     return hipGetLastError();
 }
 
