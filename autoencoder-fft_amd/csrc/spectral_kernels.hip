@@ -17,6 +17,8 @@
 // load instruction; each thread owns two bins (one float4) and a TR x TC register tile of outputs.
 #include "internal.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace aefft {
@@ -31,12 +33,12 @@ __device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b)
 // load, so a wave reads 512 B / 1 KiB contiguous), threadIdx.y = up to 4 row tiles that share
 // the B operand through L1.  Each thread owns a TR x TC register tile of outputs.
 template <int VEC, int TR, int TC>
-__device__ __forceinline__ void contract_body(const Contract& q, int zblk)
+__device__ __forceinline__ void contract_body(const Contract& q, int bx, int by, int zblk)
 {
     using V = typename std::conditional<VEC == 2, float4, float2>::type;
-    const long grp = (long)blockIdx.x * 64 + threadIdx.x;       // index of the bin group
+    const long grp = (long)bx * 64 + threadIdx.x;       // index of the bin group
     if (grp * VEC >= q.P) return;
-    const int r0 = (blockIdx.y * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
+    const int r0 = (by * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
     if (r0 >= q.R || c0 >= q.C) return;
     const V* Ap = reinterpret_cast<const V*>(q.A);
     const V* A2p = reinterpret_cast<const V*>(q.A2);
@@ -63,7 +65,10 @@ __device__ __forceinline__ void contract_body(const Contract& q, int zblk)
     for (int j = 0; j < TC; ++j) { const int cc = (c0 + j < q.C) ? c0 + j : q.C - 1; boff[j] = (cc * q.b_c) / VEC + bgrp; }
     const long a_kv = q.a_k / VEC, b_kv = q.b_k / VEC;
     const float sa = q.conjA ? -1.f : 1.f, sb = q.conjB ? -1.f : 1.f;
-    const float binv = q.preDivB;
+    // x/dM as x*(1/dM): exact for power-of-two dM, <= 1 ulp otherwise (the reference itself is built with
+    // --use_fast_math, Makefile:18, i.e. its division is already approximate)
+    const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
+    const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
 
     float2 acc[VEC][TR][TC];
 #pragma unroll
@@ -75,7 +80,10 @@ __device__ __forceinline__ void contract_body(const Contract& q, int zblk)
 
     const bool dc_thread = (grp == 0);
     if (live) {
-#pragma unroll 2
+        // deep unroll: the loop is latency bound (operands come from L2 / Infinity Cache), so keep
+        // UNR iterations of loads in flight per wave
+        constexpr int UNR = (TR * TC * VEC <= 8) ? 8 : ((TR * TC * VEC <= 16) ? 4 : 2);
+#pragma unroll UNR
         for (int k = 0; k < q.K; ++k) {
             V a[TR], b[TC];
 #pragma unroll
@@ -95,12 +103,8 @@ __device__ __forceinline__ void contract_body(const Contract& q, int zblk)
 #pragma unroll
             for (int j = 0; j < TC; ++j) {
                 float* bf = reinterpret_cast<float*>(&b[j]);
-                if (binv != 0.f) {
 #pragma unroll
-                    for (int e = 0; e < 2 * VEC; ++e) bf[e] = bf[e] / binv;
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) bf[2 * v + 1] *= sb;
+                for (int v = 0; v < VEC; ++v) { bf[2 * v] *= bmul; bf[2 * v + 1] *= bmul * sb; }
             }
 #pragma unroll
             for (int i = 0; i < TR; ++i) {
@@ -138,19 +142,38 @@ __device__ __forceinline__ void contract_body(const Contract& q, int zblk)
             for (int v = 0; v < VEC; ++v) {
                 float2 val = acc[v][i][j];
                 if (v == 0 && q.bias && !q.biasAfterFirst && dc_thread) val.x += q.bias[rr[i]] * q.biasScale;
-                if (q.postDiv != 0.f) { val.x /= q.postDiv; val.y /= q.postDiv; }
-                of[2 * v] = val.x; of[2 * v + 1] = val.y;
+                of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
             }
             Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
         }
 }
 
-template <int VEC, int TR, int TC>
-__global__ __launch_bounds__(256) void contract_kernel(const Contract2 qq, int z0)
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs by linear id, and every
+// XCD has its own 4 MiB L2.  Bins are independent, so the launch is 1-D and decoded such that all
+// workgroups whose bin tile is congruent to x mod 8 land on XCD x: each L2 then caches 1/8 of every
+// operand instead of all of it (8x less fabric traffic; speed only -- any placement is correct).
+struct BlockId { int bx, by, bz; bool ok; };
+__device__ __forceinline__ BlockId xcd_decode(int gx, int gy, int gz)
 {
-    // grid.z = [0, z0) -> problem 0, [z0, ...) -> problem 1
-    if ((int)blockIdx.z < z0) contract_body<VEC, TR, TC>(qq.q[0], blockIdx.z);
-    else contract_body<VEC, TR, TC>(qq.q[1], blockIdx.z - z0);
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int nbx8 = (gx + 7) >> 3;
+    BlockId b;
+    b.bx = (slot % nbx8) * 8 + xcd;
+    const int rest = slot / nbx8;
+    b.by = rest % gy; b.bz = rest / gy;
+    b.ok = b.bx < gx && b.bz < gz;
+    return b;
+}
+static unsigned xcd_grid(long gx, int gy, int gz) { return (unsigned)(((gx + 7) / 8) * 8 * gy * gz); }
+
+template <int VEC, int TR, int TC>
+__global__ __launch_bounds__(256) void contract_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
+{
+    const BlockId b = xcd_decode(gx, gy, gz);
+    if (!b.ok) return;
+    // z = [0, z0) -> problem 0, [z0, ...) -> problem 1
+    if (b.bz < z0) contract_body<VEC, TR, TC>(qq.q[0], b.bx, b.by, b.bz);
+    else contract_body<VEC, TR, TC>(qq.q[1], b.bx, b.by, b.bz - z0);
 }
 
 template <int VEC, int TR, int TC> static hipError_t contract_tile(const Contract2& qq, hipStream_t st)
@@ -165,7 +188,340 @@ template <int VEC, int TR, int TC> static hipError_t contract_tile(const Contrac
         z[p] = (q.C + TC - 1) / TC;
     }
     for (int p = 0; p < qq.n; ++p) gy = std::max(gy, ((qq.q[p].R + TR - 1) / TR + by - 1) / by);
-    contract_kernel<VEC, TR, TC><<<dim3((unsigned)gx, gy, z[0] + z[1]), dim3(64, by), 0, st>>>(qq, z[0]);
+    const int gz = z[0] + z[1];
+    contract_kernel<VEC, TR, TC><<<dim3(xcd_grid(gx, gy, gz)), dim3(64, by), 0, st>>>(qq, (int)gx, gy, gz, z[0]);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Lean variant of the register-tile kernel for the shapes the training loop actually launches.
+// PMC showed the generic kernel issue-bound on bookkeeping (5 VALU instructions per useful FMA:
+// 64-bit address arithmetic per load, sign and scale multiplies per operand element).  Here
+//   * operands are fetched with buffer loads: a per-lane 32-bit byte offset computed once, the K
+//     stride advanced in a scalar register (no vector address arithmetic in the loop),
+//   * conjugation is folded into the FMA signs (template flags),
+//   * the operand scaling x/dM is applied once to the sum (sum_d (x/dM) c == (sum_d x c)/dM up to
+//     float32 rounding; power-of-two dM: bit-identical unless an intermediate is subnormal).
+// ------------------------------------------------------------------------------------------
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct BufLoad;
+template <> struct BufLoad<1> {
+    typedef float2 T;
+    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+    { v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); return make_float2(__int_as_float(v.x), __int_as_float(v.y)); }
+};
+template <> struct BufLoad<2> {
+    typedef float4 T;
+    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+    { v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)); }
+};
+
+template <bool CA, bool CB> __device__ __forceinline__ void cfma_s(float2& acc, float ax, float ay, float bx, float by)
+{
+    if (CA && !CB) { acc.x += ax * bx + ay * by; acc.y += ax * by - ay * bx; }        // conj(a) * b
+    else if (CB && !CA) { acc.x += ax * bx + ay * by; acc.y += ay * bx - ax * by; }   // a * conj(b)
+    else if (CA && CB) { acc.x += ax * bx - ay * by; acc.y -= ax * by + ay * bx; }    // conj(a*b)
+    else { acc.x += ax * bx - ay * by; acc.y += ax * by + ay * bx; }
+}
+
+template <int VEC, int TR, int TC, bool CA, bool CB, bool DIFF>
+__device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, int by, int zblk)
+{
+    using L = BufLoad<VEC>;
+    using V = typename L::T;
+    const long grp = (long)bx * 64 + threadIdx.x;
+    if (grp * VEC >= q.P) return;
+    const int r0 = (by * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
+    if (r0 >= q.R || c0 >= q.C) return;
+    long bgrp = grp;
+    bool live = true;
+    if (VEC == 1 && q.upNx) {
+        const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
+        const int i = (int)(grp / Nyr), j = (int)(grp - (long)i * Nyr);
+        int si = -1, sj = -1;
+        if (i < q.upNxs / 2) si = i;
+        else if (i > q.upNx - q.upNxs / 2) si = i - q.upNx + q.upNxs;
+        else if (i == q.upNx / 2) si = q.upNxs / 2;
+        if (j < Nyrs - 1) sj = j;
+        else if (j == Nyr - 1) sj = Nyrs - 1;
+        live = (si >= 0 && sj >= 0);
+        bgrp = live ? (long)si * Nyrs + sj : 0;
+    }
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, 0xFFFFFFFFu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DIFF ? q.A2 : q.A), 0, 0xFFFFFFFFu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned aoff[TR], boff[TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { const int rr = (r0 + i < q.R) ? r0 + i : q.R - 1; aoff[i] = (unsigned)((rr * q.a_r + grp * VEC) * 8); }
+#pragma unroll
+    for (int j = 0; j < TC; ++j) { const int cc = (c0 + j < q.C) ? c0 + j : q.C - 1; boff[j] = (unsigned)((cc * q.b_c + bgrp * VEC) * 8); }
+    const unsigned a_ks = (unsigned)(q.a_k * 8), b_ks = (unsigned)(q.b_k * 8);
+
+    float2 acc[VEC][TR][TC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j) acc[v][i][j] = make_float2(0.f, 0.f);
+
+    if (live) {
+        constexpr int UNR = (TR * TC * VEC <= 8) ? 8 : ((TR * TC * VEC <= 16) ? 4 : 2);
+        unsigned sa = 0, sb = 0;
+#pragma unroll UNR
+        for (int k = 0; k < q.K; ++k) {
+            V a[TR], b[TC];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) a[i] = L::ld(ra, aoff[i], sa);
+#pragma unroll
+            for (int j = 0; j < TC; ++j) b[j] = L::ld(rb, boff[j], sb);
+            if (DIFF) {
+#pragma unroll
+                for (int i = 0; i < TR; ++i) {
+                    const V a2 = L::ld(ra2, aoff[i], sa);
+                    float* af = reinterpret_cast<float*>(&a[i]);
+                    const float* a2f = reinterpret_cast<const float*>(&a2);
+#pragma unroll
+                    for (int e = 0; e < 2 * VEC; ++e) af[e] -= a2f[e];
+                }
+            }
+            sa += a_ks; sb += b_ks;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) {
+                        const float* af = reinterpret_cast<const float*>(&a[i]);
+                        const float* bf = reinterpret_cast<const float*>(&b[j]);
+                        cfma_s<CA, CB>(acc[v][i][j], af[2 * v], af[2 * v + 1], bf[2 * v], bf[2 * v + 1]);
+                    }
+        }
+    }
+    const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
+    const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
+    V* Op = reinterpret_cast<V*>(q.Out);
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            if (r0 + i >= q.R || c0 + j >= q.C) continue;
+            V o;
+            float* of = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float2 val = make_float2(acc[v][i][j].x * bmul, acc[v][i][j].y * bmul);
+                if (v == 0 && q.bias && grp == 0) val.x += q.bias[r0 + i] * q.biasScale;
+                of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
+            }
+            Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
+        }
+}
+
+// FL: 0 = plain (conv_k), 1 = a*conj(b) with fused subtraction (the S contraction),
+//     2 = dual launch: problem 0 conj(a)*b (dc), problem 1 a*conj(b) (df)
+template <int VEC, int TR, int TC, int FL>
+__global__ __launch_bounds__(256) void contract_fast_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
+{
+    const BlockId b = xcd_decode(gx, gy, gz);
+    if (!b.ok) return;
+    if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false>(qq.q[0], b.bx, b.by, b.bz);
+    else if (FL == 1) contract_fast_body<VEC, TR, TC, false, true, true>(qq.q[0], b.bx, b.by, b.bz);
+    else {
+        if (b.bz < z0) contract_fast_body<VEC, TR, TC, true, false, false>(qq.q[0], b.bx, b.by, b.bz);
+        else contract_fast_body<VEC, TR, TC, false, true, false>(qq.q[1], b.bx, b.by, b.bz - z0);
+    }
+}
+
+template <int VEC, int TR, int TC, int FL> static hipError_t contract_fast_tile(const Contract2& qq, hipStream_t st)
+{
+    long gx = 0; int gy = 0, by = 1, z[2] = {0, 0};
+    for (int p = 0; p < qq.n; ++p) {
+        const Contract& q = qq.q[p];
+        const long groups = (q.P + VEC - 1) / VEC;
+        const int rtiles = (q.R + TR - 1) / TR;
+        gx = std::max(gx, (groups + 63) / 64);
+        by = std::max(by, rtiles < 4 ? rtiles : 4);
+        z[p] = (q.C + TC - 1) / TC;
+    }
+    for (int p = 0; p < qq.n; ++p) gy = std::max(gy, ((qq.q[p].R + TR - 1) / TR + by - 1) / by);
+    const int gz = z[0] + z[1];
+    contract_fast_kernel<VEC, TR, TC, FL><<<dim3(xcd_grid(gx, gy, gz)), dim3(64, by), 0, st>>>(qq, (int)gx, gy, gz, z[0]);
+    return hipGetLastError();
+}
+
+// which lean instantiation (if any) serves this launch: -1 = none (generic kernel)
+static int contract_fast_class(const Contract2& qq)
+{
+    auto fits32 = [](const Contract& q) {
+        const double a = ((double)(q.R - 1) * q.a_r + (double)(q.K - 1) * q.a_k + q.P) * 8.0;
+        const double b = ((double)(q.C - 1) * q.b_c + (double)(q.K - 1) * q.b_k + q.P) * 8.0;
+        return a < 4.0e9 && b < 4.0e9;
+    };
+    for (int p = 0; p < qq.n; ++p) if (!fits32(qq.q[p]) || (!qq.q[p].biasAfterFirst && qq.q[p].bias)) return -1;
+    const Contract& a = qq.q[0];
+    if (qq.n == 1) {
+        if (!a.conjA && !a.conjB && !a.A2) return 0;
+        if (!a.conjA && a.conjB && a.A2 && !a.upNx) return 1;
+        return -1;
+    }
+    const Contract& b = qq.q[1];
+    if (a.conjA && !a.conjB && !a.A2 && !a.upNx && !b.conjA && b.conjB && !b.A2 && !b.upNx) return 2;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-blocked variant for channel-heavy contractions (K >= 8, R, C >= 8: the inner pairs, where the
+// planes are small and every operand is re-used many times).  A workgroup owns BT = 32 consecutive
+// bins and an RB x CB = 16 x 16 block of outputs; the K loop runs in chunks of KC = 4 staged through
+// LDS, so each operand element is fetched from L2 once per workgroup instead of once per register
+// tile.  Eight half-waves (32 lanes = 32 bins) each own a 4 x 8 register tile; LDS reads are
+// conflict-free (a half-wave reads 256 contiguous bytes).  conj / pre-division / the fused
+// subtraction are applied when the tile is written to LDS, so the inner loop is pure complex FMA.
+// ------------------------------------------------------------------------------------------
+constexpr int LB_BT = 32, LB_RB = 16, LB_CB = 16, LB_KC = 4;
+
+__device__ __forceinline__ void contract_lds_body(const Contract& q, int bx, int by, int zblk, float2* As, float2* Bs)
+{
+    const int tid = threadIdx.x;
+    const long bin0 = (long)bx * LB_BT;
+    const int r0 = by * LB_RB, c0 = zblk * LB_CB;
+    if (r0 >= q.R || c0 >= q.C) return;             // uniform per workgroup
+    const int lane = tid & 31, grp = tid >> 5;
+    const int gr = (grp >> 1) * 4, gc = (grp & 1) * 8;
+    const long bin = bin0 + lane;
+    const float sa = q.conjA ? -1.f : 1.f, sb = q.conjB ? -1.f : 1.f;
+    const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
+    const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
+
+    // zero-pad remap of the B operand: source bin of this thread's destination bin (or none)
+    long sbin = bin;
+    bool live = bin < q.P;
+    if (q.upNx && live) {
+        const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
+        const int i = (int)(bin / Nyr), j = (int)(bin - (long)i * Nyr);
+        int si = -1, sj = -1;
+        if (i < q.upNxs / 2) si = i;
+        else if (i > q.upNx - q.upNxs / 2) si = i - q.upNx + q.upNxs;
+        else if (i == q.upNx / 2) si = q.upNxs / 2;
+        if (j < Nyrs - 1) sj = j;
+        else if (j == Nyr - 1) sj = Nyrs - 1;
+        live = (si >= 0 && sj >= 0);
+        sbin = (long)si * Nyrs + sj;
+    }
+    // a whole tile without a live bin only stores zeros (+bias): skip the K loop (workgroup-uniform vote)
+    const int any_live = __syncthreads_or(live ? 1 : 0);
+
+    float2 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = make_float2(0.f, 0.f);
+
+    if (any_live) {
+        // each thread stages 8 A and 8 B elements per K chunk: (kk, row) = segment grp + 8u of its 32-bin column.
+        // Global loads for chunk k0+KC are issued into registers BEFORE the FMAs of chunk k0 (software prefetch).
+        constexpr int NA = LB_KC * LB_RB / 8, NB = LB_KC * LB_CB / 8;
+        float2 va[NA], va2[NA], vb[NB];
+        // branch-free: every load is issued unconditionally from a clamped (always valid) address and
+        // masked afterwards -- a load inside a per-lane conditional makes hipcc wait for it at the join,
+        // which serialises the whole batch (cdna_hip_programming.md, "register or load" trap).
+        const long cbin = bin < q.P ? bin : q.P - 1;
+        const long csbin = live ? sbin : 0;
+        const bool hasA2 = q.A2 != nullptr;
+        const float2* A2p = hasA2 ? q.A2 : q.A;
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int seg = grp + 8 * u, kk = seg / LB_RB, r = seg - kk * LB_RB;
+                const int kq = (k0 + kk < q.K) ? k0 + kk : q.K - 1;
+                const int rr = (r0 + r < q.R) ? r0 + r : q.R - 1;
+                const long off = rr * q.a_r + kq * q.a_k + cbin;
+                va[u] = q.A[off];
+                if (hasA2) va2[u] = A2p[off];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int seg = grp + 8 * u, kk = seg / LB_CB, c = seg - kk * LB_CB;
+                const int kq = (k0 + kk < q.K) ? k0 + kk : q.K - 1;
+                const int cc = (c0 + c < q.C) ? c0 + c : q.C - 1;
+                vb[u] = q.B[kq * q.b_k + cc * q.b_c + csbin];
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < q.K; k0 += LB_KC) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int kk = (grp + 8 * u) / LB_RB;
+                float2 v = va[u];
+                if (hasA2) { v.x -= va2[u].x; v.y -= va2[u].y; }
+                v.y *= sa;
+                if (!(k0 + kk < q.K && bin < q.P)) v = make_float2(0.f, 0.f);
+                As[(grp + 8 * u) * LB_BT + lane] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int kk = (grp + 8 * u) / LB_CB;
+                float2 v = vb[u];
+                v.x *= bmul; v.y *= bmul * sb;
+                if (!(k0 + kk < q.K && live)) v = make_float2(0.f, 0.f);
+                Bs[(grp + 8 * u) * LB_BT + lane] = v;
+            }
+            __syncthreads();
+            if (k0 + LB_KC < q.K) fetch(k0 + LB_KC);
+#pragma unroll
+            for (int kk = 0; kk < LB_KC; ++kk) {
+                float2 a[4], b[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = As[(kk * LB_RB + gr + i) * LB_BT + lane];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = Bs[(kk * LB_CB + gc + j) * LB_BT + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cfma(acc[i][j], a[i], b[j]);
+            }
+            __syncthreads();
+        }
+    }
+    if (bin >= q.P) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + gr + i, c = c0 + gc + j;
+            if (r >= q.R || c >= q.C) continue;
+            float2 val = acc[i][j];
+            if (q.bias && bin == 0) val.x += q.bias[r] * q.biasScale;
+            val.x *= omul; val.y *= omul;
+            q.Out[r * q.o_r + c * q.o_c + bin] = val;
+        }
+}
+
+__global__ __launch_bounds__(256) void contract_lds_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
+{
+    __shared__ float2 As[LB_KC * LB_RB * LB_BT];
+    __shared__ float2 Bs[LB_KC * LB_CB * LB_BT];
+    const BlockId b = xcd_decode(gx, gy, gz);
+    if (!b.ok) return;
+    if (b.bz < z0) contract_lds_body(qq.q[0], b.bx, b.by, b.bz, As, Bs);
+    else contract_lds_body(qq.q[1], b.bx, b.by, b.bz - z0, As, Bs);
+}
+
+static bool contract_wants_lds(const Contract& q) { return q.K >= 16 && q.R >= 8 && q.C >= 8; }
+
+static hipError_t contract_lds_launch(const Contract2& qq, hipStream_t st)
+{
+    long gx = 0; int gy = 0, z[2] = {0, 0};
+    for (int p = 0; p < qq.n; ++p) {
+        const Contract& q = qq.q[p];
+        gx = std::max(gx, (q.P + LB_BT - 1) / LB_BT);
+        gy = std::max(gy, (q.R + LB_RB - 1) / LB_RB);
+        z[p] = (q.C + LB_CB - 1) / LB_CB;
+    }
+    contract_lds_kernel<<<dim3(xcd_grid(gx, gy, z[0] + z[1])), 256, 0, st>>>(qq, (int)gx, gy, z[0] + z[1], z[0]);
     return hipGetLastError();
 }
 
@@ -185,6 +541,12 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         even = even && contract_even(q);          // the float4 path needs 16-byte aligned plane offsets and no remap
         Rmin = std::min(Rmin, q.R); Cmin = std::min(Cmin, q.C);
     }
+    static const char* force = getenv("AEFFT_CONTRACT");     // dev switch: reg | lds
+    bool lds = true;
+    for (int p = 0; p < qq.n; ++p) lds = lds && contract_wants_lds(qq.q[p]);
+    lds = false;                                                // measured slower than the lean register kernel on MI355X
+    if (force && force[0] == 'l') lds = true;
+    if (lds) return contract_lds_launch(qq, st);
     // start from the largest register tile the shapes allow and shrink until the launch has enough waves
     int tr = Rmin >= 4 ? 4 : (Rmin >= 2 ? 2 : 1), tc = Cmin >= 4 ? 4 : (Cmin >= 2 ? 2 : 1), vec = even ? 2 : 1;
     auto waves = [&](int v, int r, int c) {
@@ -195,6 +557,19 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
     const long want = 2048;
     if (waves(vec, tr, tc) < want && vec == 2) vec = 1;
     if (waves(vec, tr, tc) < want && tr == 4) tr = 2;
+    static const char* tile = getenv("AEFFT_TILE");       // dev switch: "v,r,c"
+    if (tile) { int v_, r_, c_; if (sscanf(tile, "%d,%d,%d", &v_, &r_, &c_) == 3) { if (even || v_ == 1) vec = v_; tr = std::min(r_, tr == 1 ? 1 : (Rmin >= r_ ? r_ : tr)); tc = std::min(c_, Cmin >= c_ ? c_ : tc); } }
+    static const char* nofast = getenv("AEFFT_NOFAST");
+    const int fc = nofast ? -1 : contract_fast_class(qq);
+    if (fc >= 0 && tr >= 2 && tc >= 2) {
+#define AEFFT_CF(V, R_, C_) if (vec == V && tr == R_ && tc == C_) { \
+        if (fc == 0) return contract_fast_tile<V, R_, C_, 0>(qq, st); \
+        if (fc == 1) return contract_fast_tile<V, R_, C_, 1>(qq, st); \
+        return contract_fast_tile<V, R_, C_, 2>(qq, st); }
+        AEFFT_CF(2, 4, 4) AEFFT_CF(2, 4, 2) AEFFT_CF(2, 2, 4) AEFFT_CF(2, 2, 2)
+        AEFFT_CF(1, 4, 4) AEFFT_CF(1, 4, 2) AEFFT_CF(1, 2, 4) AEFFT_CF(1, 2, 2)
+#undef AEFFT_CF
+    }
 #define AEFFT_CT(V, R_, C_) if (vec == V && tr == R_ && tc == C_) return contract_tile<V, R_, C_>(qq, st);
     AEFFT_CT(2, 4, 4) AEFFT_CT(2, 4, 2) AEFFT_CT(2, 2, 4) AEFFT_CT(2, 2, 2) AEFFT_CT(2, 4, 1) AEFFT_CT(2, 1, 4) AEFFT_CT(2, 2, 1) AEFFT_CT(2, 1, 2) AEFFT_CT(2, 1, 1)
     AEFFT_CT(1, 4, 4) AEFFT_CT(1, 4, 2) AEFFT_CT(1, 2, 4) AEFFT_CT(1, 2, 2) AEFFT_CT(1, 4, 1) AEFFT_CT(1, 1, 4) AEFFT_CT(1, 2, 1) AEFFT_CT(1, 1, 2) AEFFT_CT(1, 1, 1)

@@ -120,14 +120,12 @@ def main():
     frames = synth_frames(torch, B, D, N, dev, first_index=rank * B)      # each rank its own shard of the global batch
     recon = torch.empty_like(frames)
     mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
-    gbuf = net.grad_buffer()
+    dp = importlib.import_module("autoencoder-fft_amd.dp")
+    dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
     del0 = 0.2                                                            # autoencoder.cpp:87
 
     def step():
-        net.step_grad(frames, recon)
-        if world > 1:
-            dist.all_reduce(gbuf)                                         # RCCL sum of the packed kernel-support gradients
-        net.step_apply(del0, 0, 0, 1.0 / world, mse)
+        dpstep(frames, recon, del0, 0, 0, mse)
 
     def fence():
         if world > 1:
