@@ -37,6 +37,7 @@ SIGNATURES = {
     "aefft_ctx_destroy": (None, [_vp]),
     "aefft_last_error": (C.c_char_p, [_vp]),
     "aefft_sync": (_i, [_vp]),
+    "aefft_ctx_set_concurrency": (_i, [_vp, _i]),
     "aefft_stream": (_vp, [_vp]),
     "aefft_version": (C.c_char_p, []),
     "aefft_r2c": (_i, [_vp, _fp, _fp, _l, _i, _i]),
@@ -251,6 +252,9 @@ class Context:
                                                  _ptr(dc), _ptr(db), _ptr(df), _ptr(dp), _ptr(ddc), _ptr(ddb), _ptr(ddf), _ptr(ddp),
                                                  B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, 1 if tied else 0,
                                                  0 if semantics == "gpu" else 1))
+
+    def set_concurrency(self, on=True):
+        self.check(self.L.aefft_ctx_set_concurrency(self.h, 1 if on else 0))
 
     # ---- profiling ----
     def prof_enable(self, on=True):

@@ -29,6 +29,7 @@ struct aefft_ctx {
     hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
+    bool concurrency = true;         // spread independent per-pair work over the side streams
     static const int NAUX = 4;
     hipStream_t aux[NAUX] = {};      // side streams for independent per-pair work (created on first net)
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {};
@@ -136,6 +137,7 @@ extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
 
 extern "C" const char* aefft_last_error(const aefft_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" int aefft_sync(aefft_ctx* ctx) { if (!ctx) return AEFFT_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return AEFFT_OK; }
+extern "C" int aefft_ctx_set_concurrency(aefft_ctx* ctx, int enable) { if (!ctx) return AEFFT_EINVAL; ctx->concurrency = enable != 0; return AEFFT_OK; }
 extern "C" void* aefft_stream(aefft_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" int aefft_prof_enable(aefft_ctx* ctx, int enable)
@@ -1013,7 +1015,7 @@ static int join_streams(aefft_ctx* ctx)
     }
     return AEFFT_OK;
 }
-static bool use_side_streams(const aefft_net* n) { return n->pruned && n->L > 1 && n->ctx->aux[0] != nullptr; }
+static bool use_side_streams(const aefft_net* n) { return n->ctx->concurrency && n->pruned && n->L > 1 && n->ctx->aux[0] != nullptr; }
 
 extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* recon_d)
 {

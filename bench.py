@@ -151,10 +151,11 @@ def main():
     roof = None
     if rank == 0 and not a.no_roofline:
         # per-kernel HIP events on the stream the kernels run on, over the same step
-        ctx.prof_enable(True); ctx.prof_reset()
+        # (side streams off: overlapped kernels would be charged each other's time)
+        ctx.set_concurrency(False); ctx.prof_enable(True); ctx.prof_reset()
         for _ in range(3):
             net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
-        prof = ctx.prof_read(); ctx.prof_enable(False)
+        prof = ctx.prof_read(); ctx.prof_enable(False); ctx.set_concurrency(True)
         tot = sum(v["ms"] for v in prof.values())
         name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         per_launch_bytes = dom["bytes"] / dom["launches"]

@@ -134,16 +134,23 @@ def test_vector_entry_points_fft_mode(wrap):
         off += sz
     Cs = cf[:W].view(np.complex64).reshape(dM, D, n, n // 2 + 1)
     assert np.abs(Cs - cfreq[0]).max() < 1e-5 * np.abs(cfreq[0]).max()
-    # second call: cache hit (spectra loaded from net_cfreq), fft_l = 0, then the 100-iteration burst
+    # second call: cache hit (spectra loaded from net_cfreq) with fft_l = 0: only layers.back() is produced (Appendix B-6)
     lay2 = np.zeros_like(lay)
-    wrap.w_fft_pair(_p(x), _p(lay2), _p(cc), _p(bb), _p(ff), _p(pp), _p(cf), C.byref(nc), D, dM, N, Nk, s, 0, 1, C.c_float(0.2), 0)
+    wrap.w_fft_pair(_p(x), _p(lay2), _p(cc), _p(bb), _p(ff), _p(pp), _p(cf), C.byref(nc), D, dM, N, Nk, s, 0, 0, C.c_float(0.2), 0)
+    assert np.all(lay2[:sizes[0]] == 0)
+    assert np.abs(lay2[-sizes[3]:] - layers[4].ravel()).max() < 1e-4 * np.abs(layers[4]).max()
+    # third call: fft_l = 1 (the burst trains on layers[1], layers[3]) then the 100-iteration backprop_fft
+    # del0 = 0.01: at the reference default 0.2 the clipped (sign-like) updates make the 100-iteration trajectory chaotic --
+    # the float32 replay of the oracle itself ends 0.12 (25% of the total change) away from its float64 master --
+    # so a trajectory comparison is only meaningful in the smooth regime (float32 replay error 6e-6 here).
+    wrap.w_fft_pair(_p(x), _p(lay2), _p(cc), _p(bb), _p(ff), _p(pp), _p(cf), C.byref(nc), D, dM, N, Nk, s, 1, 1, C.c_float(0.01), 0)
     assert np.abs(lay2[-sizes[3]:] - layers[4].ravel()).max() < 1e-4 * np.abs(layers[4]).max()
     r = R.backprop_fft(layers[1], layers[1], layers[3], cfreq[0], c.astype(np.float64), cfreq[1], f.astype(np.float64),
-                       b.astype(np.float64), p.astype(np.float64), 0.2, n_iter=100)
+                       b.astype(np.float64), p.astype(np.float64), 0.01, n_iter=100)
     dw = np.abs(r["c"] - c).max()
     assert dw > 1e-3
     for a, k in ((cc, "c"), (ff, "f"), (bb, "b"), (pp, "p")):
-        assert np.abs(a - r[k]).max() < 1e-5 + 5e-3 * dw, (k, np.abs(a - r[k]).max(), dw)
+        assert np.abs(a - r[k]).max() < 2e-5 + 1e-3 * dw, (k, np.abs(a - r[k]).max(), dw)
     Cs = cf[:W].view(np.complex64).reshape(dM, D, n, n // 2 + 1)
     assert np.abs(Cs - r["C"]).max() < 5e-3 * np.abs(r["C"] - cfreq[0]).max() + 1e-4 * np.abs(r["C"]).max()
 
