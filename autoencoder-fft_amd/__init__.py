@@ -136,6 +136,13 @@ class Context:
     def sync(self):
         self.check(self.L.aefft_sync(self.h))
 
+    def torch_stream(self):
+        """The library's stream as a torch stream object (so collectives / torch ops can be ordered on it)."""
+        ptr = self.L.aefft_stream(self.h)
+        if not ptr:
+            return self.torch.cuda.default_stream(self.device)
+        return self.torch.cuda.ExternalStream(ptr, device=f"cuda:{self.device}")
+
     # ---- helpers on torch tensors (float32 / complex64, contiguous, on this device) ----
     def empty(self, *shape, dtype=None):
         t = self.torch

@@ -29,7 +29,7 @@ struct aefft_ctx {
     hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
-    bool concurrency = true;         // spread independent per-pair work over the side streams
+    bool concurrency = false;        // spread independent per-pair work over the side streams (measured slower on MI355X: off by default)
     static const int NAUX = 4;
     hipStream_t aux[NAUX] = {};      // side streams for independent per-pair work (created on first net)
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {};

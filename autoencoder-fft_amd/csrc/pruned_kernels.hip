@@ -21,9 +21,9 @@ namespace aefft {
 
 __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int N, float sign)
 {
-    // e^{sign * -2 pi i * pos*off / N}; pos in [0,N), off may be negative
-    int r = (int)(((long)pos * off) % N);
-    if (r < 0) r += N;
+    // e^{sign * -2 pi i * pos*off / N}; pos in [0,N), off may be negative; N is a power of two, so the
+    // two's-complement AND is the non-negative residue (a 64-bit '%' costs hundreds of cycles on the GPU)
+    const int r = (pos * off) & (N - 1);
     float2 w = tw[r * (TW_N / N)];
     w.y *= sign;
     return w;
@@ -31,28 +31,28 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
 
 template <int NK, int NL>
 __global__ __launch_bounds__(256) void kspec_kernel(const float* __restrict__ kern, float2* __restrict__ K,
-                                                    const float2* __restrict__ tw, int Nx, int Ny, int rows_per_chunk)
+                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny,
+                                                    int rows_per_chunk, int ppb)
 {
     extern __shared__ float2 lds[];
     const int Nyr = Ny / 2 + 1;
     float2* rowph = lds;                                 // [rows_per_chunk][NK]
     float2* colph = lds + rows_per_chunk * NK;           // [Nyr][NL]
-    float* taps = reinterpret_cast<float*>(colph + Nyr * NL);
-    const long plane = blockIdx.x;
+    float* taps = reinterpret_cast<float*>(colph + Nyr * NL);   // [ppb][NK*NL]
+    const long plane0 = (long)blockIdx.x * ppb;
+    const int np = (int)min((long)ppb, planes - plane0);
     const int i0 = blockIdx.y * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
+    // the phase tables depend on (Nx, Ny) only: built once per workgroup, shared by its ppb planes
     for (int t = threadIdx.x; t < nrows * NK; t += 256) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, 1.f);
     for (int t = threadIdx.x; t < Nyr * NL; t += 256) colph[t] = phase(tw, t / NL, t % NL - NL / 2, Ny, 1.f);
-    for (int t = threadIdx.x; t < NK * NL; t += 256) taps[t] = kern[plane * NK * NL + t];
+    for (int t = threadIdx.x; t < np * NK * NL; t += 256) taps[t] = kern[plane0 * NK * NL + t];
     __syncthreads();
-    float c[NK][NL];
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int l = 0; l < NL; ++l) c[k][l] = taps[k * NL + l];
-    float2* dst = K + (plane * Nx + i0) * (long)Nyr;
-    for (int idx = threadIdx.x; idx < nrows * Nyr; idx += 256) {
-        const int i = idx / Nyr, j = idx % Nyr;
+    const int nb = nrows * Nyr;
+    for (int idx = threadIdx.x; idx < np * nb; idx += 256) {
+        const int pl = idx / nb, bin = idx - pl * nb;
+        const int i = bin / Nyr, j = bin - i * Nyr;
+        const float* c = taps + pl * NK * NL;
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -60,13 +60,14 @@ __global__ __launch_bounds__(256) void kspec_kernel(const float* __restrict__ ke
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const float2 cp = colph[j * NL + l];
-                v.x += c[k][l] * cp.x; v.y += c[k][l] * cp.y;
+                const float w = c[k * NL + l];
+                v.x += w * cp.x; v.y += w * cp.y;
             }
             const float2 rp = rowph[i * NK + k];
             acc.x += v.x * rp.x - v.y * rp.y;
             acc.y += v.x * rp.y + v.y * rp.x;
         }
-        dst[idx] = acc;
+        K[((plane0 + pl) * Nx + i0) * (long)Nyr + bin] = acc;
     }
 }
 
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const float2* __restrict__ D
     float2* rows = lds;                          // [RB][Nyr]
     float2* colph = rows + RB * Nyr;             // [Nyr][NL]  w_j * e^{+...}
     float2* tpart = colph + Nyr * NL;            // [JS][RB*NL]
+    float2* rowph = tpart + JS * RB * NL;        // [RB][NK]   e^{+...}
     const long plane = blockIdx.x;
     const int chunk = blockIdx.y, nchunks = gridDim.y;
     const int i0 = chunk * RB;
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const float2* __restrict__ D
         const float wj = (j == 0 || j == Ny / 2) ? 1.f : 2.f;
         colph[t] = make_float2(w.x * wj, w.y * wj);
     }
+    for (int t = threadIdx.x; t < RB * NK; t += 256) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, -1.f);
     __syncthreads();
     const int nitem = RB * NL * JS;
     for (int it = threadIdx.x; it < nitem; it += 256) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const float2* __restrict__ D
         for (int i = 0; i < RB; ++i) {
             float2 t = make_float2(0.f, 0.f);
             for (int js = 0; js < JS; ++js) { const float2 p = tpart[js * RB * NL + i * NL + l]; t.x += p.x; t.y += p.y; }
-            const float2 rp = phase(tw, i0 + i, k - NK / 2, Nx, -1.f);
+            const float2 rp = rowph[i * NK + k];
             g += t.x * rp.x - t.y * rp.y;
         }
         part[(plane * nchunks + chunk) * (NK * NL) + threadIdx.x] = g * scale;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void ksum_kernel(const float* __restrict__ par
     g[e] = s;
 }
 
-static size_t kspec_lds(int rows, int Ny, int Nk, int Nl) { return sizeof(float2) * ((size_t)rows * Nk + (size_t)(Ny / 2 + 1) * Nl) + sizeof(float) * Nk * Nl; }
+static size_t kspec_lds(int rows, int Ny, int Nk, int Nl, int ppb) { return sizeof(float2) * ((size_t)rows * Nk + (size_t)(Ny / 2 + 1) * Nl) + sizeof(float) * Nk * Nl * ppb; }
 // rows per workgroup: as many as fit ~32 KB of LDS, fewer when that would leave the chip short of workgroups
 static void kgrad_geom(long planes, int Nx, int Ny, int Nl, int* RB, int* JS)
 {
@@ -153,7 +156,7 @@ static size_t kgrad_lds(long planes, int Nx, int Ny, int Nk, int Nl)
     int RB, JS;
     kgrad_geom(planes, Nx, Ny, Nl, &RB, &JS);
     const int Nyr = Ny / 2 + 1;
-    return sizeof(float2) * ((size_t)RB * Nyr + (size_t)Nyr * Nl + (size_t)JS * RB * Nl);
+    return sizeof(float2) * ((size_t)RB * Nyr + (size_t)Nyr * Nl + (size_t)JS * RB * Nl + (size_t)RB * Nk);
 }
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl)
 {
@@ -172,16 +175,19 @@ bool pruned_supported(int Nk, int Nl, int Nx, int Ny)
 template <int NK, int NL>
 static hipError_t run_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, hipStream_t st)
 {
-    // enough workgroups to fill the chip: split each plane into row chunks when there are few planes
-    int chunks = 1;
-    while (planes * chunks < 1024 && Nx / (chunks * 2) >= 8) chunks *= 2;
+    // ~2048 bins of output per workgroup: small planes are grouped (shared phase tables), large planes are
+    // split into row chunks; at least ~1024 workgroups when the problem allows it
+    const int Nyr = Ny / 2 + 1;
+    int chunks = 1, ppb = 1;
+    while ((long)(Nx / chunks) * Nyr > 2048 && Nx / (chunks * 2) >= 1) chunks *= 2;
+    while (chunks == 1 && (long)ppb * 2 * Nx * Nyr <= 2048 && planes / (ppb * 2) >= 1024) ppb *= 2;
     const int rows = (Nx + chunks - 1) / chunks;
-    const size_t lds = kspec_lds(rows, Ny, NK, NL);
+    const size_t lds = kspec_lds(rows, Ny, NK, NL, ppb);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_kernel<NK, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    kspec_kernel<NK, NL><<<dim3((unsigned)planes, chunks), 256, lds, st>>>(k, K, tw, Nx, Ny, rows);
+    kspec_kernel<NK, NL><<<dim3((unsigned)((planes + ppb - 1) / ppb), chunks), 256, lds, st>>>(k, K, tw, planes, Nx, Ny, rows, ppb);
     return hipGetLastError();
 }
 

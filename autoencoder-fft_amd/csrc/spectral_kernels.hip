@@ -155,16 +155,25 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
 struct BlockId { int bx, by, bz; bool ok; };
 __device__ __forceinline__ BlockId xcd_decode(int gx, int gy, int gz)
 {
-    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-    const int nbx8 = (gx + 7) >> 3;
+    const int lin = blockIdx.x;
     BlockId b;
+    if (gx < 64) {
+        // too few bin tiles to give every XCD an equal share: plain order (bin tile fastest), all XCDs busy
+        b.bx = lin % gx;
+        const int rest = lin / gx;
+        b.by = rest % gy; b.bz = rest / gy;
+        b.ok = b.bz < gz;
+        return b;
+    }
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int nbx8 = (gx + 7) >> 3;
     b.bx = (slot % nbx8) * 8 + xcd;
     const int rest = slot / nbx8;
     b.by = rest % gy; b.bz = rest / gy;
     b.ok = b.bx < gx && b.bz < gz;
     return b;
 }
-static unsigned xcd_grid(long gx, int gy, int gz) { return (unsigned)(((gx + 7) / 8) * 8 * gy * gz); }
+static unsigned xcd_grid(long gx, int gy, int gz) { return gx < 64 ? (unsigned)(gx * gy * gz) : (unsigned)(((gx + 7) / 8) * 8 * gy * gz); }
 
 template <int VEC, int TR, int TC>
 __global__ __launch_bounds__(256) void contract_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
@@ -218,25 +227,29 @@ template <> struct BufLoad<2> {
     { v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)); }
 };
 
+// four scalar FMAs per complex MAC (conjugation folded into the signs); the file is built with
+// -fno-slp-vectorize because hipcc otherwise packs these into v_pk_mul/v_pk_add/v_pk_fma triples
+// (5 packed instructions per complex MAC instead of 4 plain FMAs)
 template <bool CA, bool CB> __device__ __forceinline__ void cfma_s(float2& acc, float ax, float ay, float bx, float by)
 {
-    if (CA && !CB) { acc.x += ax * bx + ay * by; acc.y += ax * by - ay * bx; }        // conj(a) * b
-    else if (CB && !CA) { acc.x += ax * bx + ay * by; acc.y += ay * bx - ax * by; }   // a * conj(b)
-    else if (CA && CB) { acc.x += ax * bx - ay * by; acc.y -= ax * by + ay * bx; }    // conj(a*b)
-    else { acc.x += ax * bx - ay * by; acc.y += ax * by + ay * bx; }
+    if (CA && !CB) { acc.x = fmaf(ax, bx, acc.x); acc.x = fmaf(ay, by, acc.x); acc.y = fmaf(ax, by, acc.y); acc.y = fmaf(-ay, bx, acc.y); }        // conj(a) * b
+    else if (CB && !CA) { acc.x = fmaf(ax, bx, acc.x); acc.x = fmaf(ay, by, acc.x); acc.y = fmaf(ay, bx, acc.y); acc.y = fmaf(-ax, by, acc.y); }   // a * conj(b)
+    else if (CA && CB) { acc.x = fmaf(ax, bx, acc.x); acc.x = fmaf(-ay, by, acc.x); acc.y = fmaf(-ax, by, acc.y); acc.y = fmaf(-ay, bx, acc.y); }  // conj(a*b)
+    else { acc.x = fmaf(ax, bx, acc.x); acc.x = fmaf(-ay, by, acc.x); acc.y = fmaf(ax, by, acc.y); acc.y = fmaf(ay, bx, acc.y); }
 }
 
-template <int VEC, int TR, int TC, bool CA, bool CB, bool DIFF>
-__device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, int by, int zblk)
+template <int VEC, int TR, int TC, bool CA, bool CB, bool DIFF, int KS>
+__device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, int by, int zblk, float* red)
 {
     using L = BufLoad<VEC>;
     using V = typename L::T;
     const long grp = (long)bx * 64 + threadIdx.x;
-    if (grp * VEC >= q.P) return;
-    const int r0 = (by * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
-    if (r0 >= q.R || c0 >= q.C) return;
+    const int ks = KS > 1 ? threadIdx.y : 0;
+    const int r0 = (KS > 1 ? by : by * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
+    const bool inside = grp * VEC < q.P && r0 < q.R && c0 < q.C;
+    if (KS == 1 && !inside) return;
     long bgrp = grp;
-    bool live = true;
+    bool live = inside;
     if (VEC == 1 && q.upNx) {
         const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
         const int i = (int)(grp / Nyr), j = (int)(grp - (long)i * Nyr);
@@ -246,7 +259,7 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
         else if (i == q.upNx / 2) si = q.upNxs / 2;
         if (j < Nyrs - 1) sj = j;
         else if (j == Nyr - 1) sj = Nyrs - 1;
-        live = (si >= 0 && sj >= 0);
+        live = inside && (si >= 0 && sj >= 0);
         bgrp = live ? (long)si * Nyrs + sj : 0;
     }
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, 0xFFFFFFFFu, 0x00020000);
@@ -268,37 +281,83 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
             for (int j = 0; j < TC; ++j) acc[v][i][j] = make_float2(0.f, 0.f);
 
     if (live) {
-        constexpr int UNR = (TR * TC * VEC <= 8) ? 8 : ((TR * TC * VEC <= 16) ? 4 : 2);
-        unsigned sa = 0, sb = 0;
-#pragma unroll UNR
-        for (int k = 0; k < q.K; ++k) {
-            V a[TR], b[TC];
+        constexpr int UNR = ((TR + TC) * VEC <= 8) ? 8 : (((TR + TC) * VEC <= 12) ? 4 : 2);   // <= ~96 operand VGPRs in flight
+        const int kq = (q.K + KS - 1) / KS;
+        const int kbeg = ks * kq, kend = (kbeg + kq < q.K) ? kbeg + kq : q.K;
+        // Explicit software pipelining: hipcc keeps "load k; wait; FMA k" order inside an unrolled loop (and sinks
+        // hoisted loads back past any branch), which exposes one full memory round trip per k (measured:
+        // 0.4 us per k).  A branch-free group of UNR iterations puts UNR*(TR+TC) loads in flight before the first wait.
+        auto group = [&](int k0, auto NU) {
+            constexpr int U = decltype(NU)::value;            // straight-line: U*(TR+TC) loads, then the FMAs -- no branch in between
+            V a[U][TR], b[U][TC], a2[DIFF ? U : 1][DIFF ? TR : 1];
 #pragma unroll
-            for (int i = 0; i < TR; ++i) a[i] = L::ld(ra, aoff[i], sa);
+            for (int u = 0; u < U; ++u) {
+                const unsigned sa = (k0 + u) * a_ks, sb = (k0 + u) * b_ks;
 #pragma unroll
-            for (int j = 0; j < TC; ++j) b[j] = L::ld(rb, boff[j], sb);
-            if (DIFF) {
+                for (int i = 0; i < TR; ++i) a[u][i] = L::ld(ra, aoff[i], sa);
 #pragma unroll
-                for (int i = 0; i < TR; ++i) {
-                    const V a2 = L::ld(ra2, aoff[i], sa);
-                    float* af = reinterpret_cast<float*>(&a[i]);
-                    const float* a2f = reinterpret_cast<const float*>(&a2);
+                for (int j = 0; j < TC; ++j) b[u][j] = L::ld(rb, boff[j], sb);
+                if (DIFF) {
 #pragma unroll
-                    for (int e = 0; e < 2 * VEC; ++e) af[e] -= a2f[e];
+                    for (int i = 0; i < TR; ++i) a2[u][i] = L::ld(ra2, aoff[i], sa);
                 }
             }
-            sa += a_ks; sb += b_ks;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (DIFF) {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+                        float* af = reinterpret_cast<float*>(&a[u][i]);
+                        const float* a2f = reinterpret_cast<const float*>(&a2[u][i]);
+#pragma unroll
+                        for (int e = 0; e < 2 * VEC; ++e) af[e] -= a2f[e];
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int i = 0; i < TR; ++i)
+#pragma unroll
+                        for (int j = 0; j < TC; ++j) {
+                            const float* af = reinterpret_cast<const float*>(&a[u][i]);
+                            const float* bf = reinterpret_cast<const float*>(&b[u][j]);
+                            cfma_s<CA, CB>(acc[v][i][j], af[2 * v], af[2 * v + 1], bf[2 * v], bf[2 * v + 1]);
+                        }
+            }
+        };
+        int k0 = kbeg;
+        for (; k0 + UNR <= kend; k0 += UNR) group(k0, std::integral_constant<int, UNR>{});
+        for (; k0 < kend; ++k0) group(k0, std::integral_constant<int, 1>{});
+    }
+    if (KS > 1) {
+        // waves 1..KS-1 park their partial tiles in LDS ([slice][value][lane]: conflict-free), wave 0 sums them in slice order
+        constexpr int NV = VEC * TR * TC * 2;
+        if (ks > 0) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
 #pragma unroll
                 for (int i = 0; i < TR; ++i)
 #pragma unroll
                     for (int j = 0; j < TC; ++j) {
-                        const float* af = reinterpret_cast<const float*>(&a[i]);
-                        const float* bf = reinterpret_cast<const float*>(&b[j]);
-                        cfma_s<CA, CB>(acc[v][i][j], af[2 * v], af[2 * v + 1], bf[2 * v], bf[2 * v + 1]);
+                        const int e = ((v * TR + i) * TC + j) * 2;
+                        red[((ks - 1) * NV + e) * 64 + threadIdx.x] = acc[v][i][j].x;
+                        red[((ks - 1) * NV + e + 1) * 64 + threadIdx.x] = acc[v][i][j].y;
                     }
         }
+        __syncthreads();
+        if (ks > 0 || !inside) return;
+#pragma unroll
+        for (int s2 = 0; s2 < KS - 1; ++s2)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) {
+                        const int e = ((v * TR + i) * TC + j) * 2;
+                        acc[v][i][j].x += red[(s2 * NV + e) * 64 + threadIdx.x];
+                        acc[v][i][j].y += red[(s2 * NV + e + 1) * 64 + threadIdx.x];
+                    }
     }
     const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
     const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
@@ -322,20 +381,21 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
 
 // FL: 0 = plain (conv_k), 1 = a*conj(b) with fused subtraction (the S contraction),
 //     2 = dual launch: problem 0 conj(a)*b (dc), problem 1 a*conj(b) (df)
-template <int VEC, int TR, int TC, int FL>
+template <int VEC, int TR, int TC, int FL, int KS>
 __global__ __launch_bounds__(256) void contract_fast_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
 {
+    __shared__ float red[KS > 1 ? (KS - 1) * VEC * TR * TC * 2 * 64 : 1];
     const BlockId b = xcd_decode(gx, gy, gz);
-    if (!b.ok) return;
-    if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false>(qq.q[0], b.bx, b.by, b.bz);
-    else if (FL == 1) contract_fast_body<VEC, TR, TC, false, true, true>(qq.q[0], b.bx, b.by, b.bz);
+    if (!b.ok) return;                                   // uniform per workgroup
+    if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false, KS>(qq.q[0], b.bx, b.by, b.bz, red);
+    else if (FL == 1) contract_fast_body<VEC, TR, TC, false, true, true, KS>(qq.q[0], b.bx, b.by, b.bz, red);
     else {
-        if (b.bz < z0) contract_fast_body<VEC, TR, TC, true, false, false>(qq.q[0], b.bx, b.by, b.bz);
-        else contract_fast_body<VEC, TR, TC, false, true, false>(qq.q[1], b.bx, b.by, b.bz - z0);
+        if (b.bz < z0) contract_fast_body<VEC, TR, TC, true, false, false, KS>(qq.q[0], b.bx, b.by, b.bz, red);
+        else contract_fast_body<VEC, TR, TC, false, true, false, KS>(qq.q[1], b.bx, b.by, b.bz - z0, red);
     }
 }
 
-template <int VEC, int TR, int TC, int FL> static hipError_t contract_fast_tile(const Contract2& qq, hipStream_t st)
+template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_fast_tile(const Contract2& qq, hipStream_t st)
 {
     long gx = 0; int gy = 0, by = 1, z[2] = {0, 0};
     for (int p = 0; p < qq.n; ++p) {
@@ -346,9 +406,10 @@ template <int VEC, int TR, int TC, int FL> static hipError_t contract_fast_tile(
         by = std::max(by, rtiles < 4 ? rtiles : 4);
         z[p] = (q.C + TC - 1) / TC;
     }
-    for (int p = 0; p < qq.n; ++p) gy = std::max(gy, ((qq.q[p].R + TR - 1) / TR + by - 1) / by);
+    if (KS > 1) by = KS;
+    for (int p = 0; p < qq.n; ++p) { const int rtiles = (qq.q[p].R + TR - 1) / TR; gy = std::max(gy, KS > 1 ? rtiles : (rtiles + by - 1) / by); }
     const int gz = z[0] + z[1];
-    contract_fast_kernel<VEC, TR, TC, FL><<<dim3(xcd_grid(gx, gy, gz)), dim3(64, by), 0, st>>>(qq, (int)gx, gy, gz, z[0]);
+    contract_fast_kernel<VEC, TR, TC, FL, KS><<<dim3(xcd_grid(gx, gy, gz)), dim3(64, by), 0, st>>>(qq, (int)gx, gy, gz, z[0]);
     return hipGetLastError();
 }
 
@@ -554,18 +615,29 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         for (int p = 0; p < qq.n; ++p) { const Contract& q = qq.q[p]; w += ((q.P + 64L * v - 1) / (64L * v)) * ((q.R + r - 1) / r) * ((q.C + c - 1) / c); }
         return w;
     };
-    const long want = 2048;
-    if (waves(vec, tr, tc) < want && vec == 2) vec = 1;
-    if (waves(vec, tr, tc) < want && tr == 4) tr = 2;
+    // Measured on MI355X (tools_mb.py sweep): these kernels are bound by the number of wave-level load
+    // instructions the texture path must process (~16 clk each, whatever their width) and by waves in flight.
+    // 16-byte loads (VEC = 2) halve the instruction count; TR = 4 only pays when the launch still has >= 4096 waves.
+    if (waves(vec, tr, tc) < 4096 && tr == 4) tr = 2;
+    if (waves(vec, tr, tc) < 1024 && vec == 2) vec = 1;
     static const char* tile = getenv("AEFFT_TILE");       // dev switch: "v,r,c"
     if (tile) { int v_, r_, c_; if (sscanf(tile, "%d,%d,%d", &v_, &r_, &c_) == 3) { if (even || v_ == 1) vec = v_; tr = std::min(r_, tr == 1 ? 1 : (Rmin >= r_ ? r_ : tr)); tc = std::min(c_, Cmin >= c_ ? c_ : tc); } }
     static const char* nofast = getenv("AEFFT_NOFAST");
     const int fc = nofast ? -1 : contract_fast_class(qq);
     if (fc >= 0 && tr >= 2 && tc >= 2) {
+        // split-K when even the shrunk tiles leave the chip short of waves and the K chain is long
+        int Kmin = 1 << 30;
+        for (int p = 0; p < qq.n; ++p) Kmin = std::min(Kmin, qq.q[p].K);
+        static const char* nosplit = getenv("AEFFT_NOSPLITK");
+        const bool splitk = !nosplit && Kmin >= 16 && waves(vec, tr, tc) < 4096 && vec * tr * tc <= 16;
 #define AEFFT_CF(V, R_, C_) if (vec == V && tr == R_ && tc == C_) { \
-        if (fc == 0) return contract_fast_tile<V, R_, C_, 0>(qq, st); \
-        if (fc == 1) return contract_fast_tile<V, R_, C_, 1>(qq, st); \
-        return contract_fast_tile<V, R_, C_, 2>(qq, st); }
+        if (V * R_ * C_ <= 16 && splitk) { \
+            if (fc == 0) return contract_fast_tile<V, R_, C_, 0, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); \
+            if (fc == 1) return contract_fast_tile<V, R_, C_, 1, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); \
+            return contract_fast_tile<V, R_, C_, 2, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); } \
+        if (fc == 0) return contract_fast_tile<V, R_, C_, 0, 1>(qq, st); \
+        if (fc == 1) return contract_fast_tile<V, R_, C_, 1, 1>(qq, st); \
+        return contract_fast_tile<V, R_, C_, 2, 1>(qq, st); }
         AEFFT_CF(2, 4, 4) AEFFT_CF(2, 4, 2) AEFFT_CF(2, 2, 4) AEFFT_CF(2, 2, 2)
         AEFFT_CF(1, 4, 4) AEFFT_CF(1, 4, 2) AEFFT_CF(1, 2, 4) AEFFT_CF(1, 2, 2)
 #undef AEFFT_CF
@@ -699,14 +771,16 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
                                                         int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
 {
     extern __shared__ float2 es[];
-    for (int d = threadIdx.x; d < dD; d += 256) {
-        float2 s = make_float2(0.f, 0.f);
-        for (int bb = 0; bb < B; ++bb) {
-            const long q = ((long)bb * dD + d) * P;
-            const float2 o = O[q], t = T[q];
-            s.x += o.x - t.x; s.y += o.y - t.y;
-        }
-        es[d] = s;
+    float* esf = reinterpret_cast<float*>(es);
+    for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
+    __syncthreads();
+    // (frame, channel) pairs spread over the threads so the B*dD DC-bin loads are all in flight at once
+    for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
+        const int d = idx % dD;
+        const long q = (long)idx * P;
+        const float2 o = O[q], t = T[q];
+        atomicAdd(&esf[2 * d], o.x - t.x);
+        atomicAdd(&esf[2 * d + 1], o.y - t.y);
     }
     __syncthreads();
     const float den = Norm * (float)B;

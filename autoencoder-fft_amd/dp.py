@@ -59,7 +59,11 @@ class DataParallelStep:
 
     def __call__(self, frames, recon, del0, maxdiff=0, sym=0, mse=None):
         self.net.step_grad(frames, recon)
-        scale = allreduce_sum_(self.gbuf, self.group)
+        # the collective is enqueued on the library's own stream: gradients -> all-reduce -> update stay ordered
+        # without any host synchronisation
+        import torch
+        with torch.cuda.stream(self.net.ctx.torch_stream()):
+            scale = allreduce_sum_(self.gbuf, self.group)
         self.net.step_apply(del0, maxdiff, sym, scale, mse)
 
     def replicas_agree(self):

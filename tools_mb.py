@@ -9,7 +9,9 @@ def bench(fn, n=30):
     for _ in range(n): fn()
     p = ctx.prof_read()["contract"]; ctx.prof_enable(False)
     return p["ms"]/p["launches"]*1e3
-for (dD,dM,N,B) in [(32,64,32,32),(16,32,64,32),(8,16,128,32),(3,8,256,32),(64,32,32,32),(32,64,32,8),(32,64,32,128)]:
+import ast
+shapes = ast.literal_eval(os.environ.get('SHAPES', '[(32,64,32,32),(16,32,64,32),(8,16,128,32),(3,8,256,32),(64,32,32,32),(32,64,32,8),(32,64,32,128)]'))
+for (dD,dM,N,B) in shapes:
     X=torch.randn(B,dD,N,N//2+1,dtype=torch.complex64,device='cuda')
     Cs=torch.randn(dM,dD,N,N//2+1,dtype=torch.complex64,device='cuda')
     b=torch.randn(dM,device='cuda')
