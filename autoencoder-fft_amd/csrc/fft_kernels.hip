@@ -121,7 +121,7 @@ __host__ __device__ constexpr int pad_len(int n) { return n + (n >> 3) + 2; }
 // transform, 0..N/8-1.  Butterfly ib reads elements ib + tt*(N/R) and writes q + S*(R*p + u)
 // with p = ib / S, q = ib % S, twiddle W_n^(p*u), n = N/S.  In place: read, barrier, write, barrier.
 template <int N, int R, int S, int DIR>
-__device__ __forceinline__ void fft_pass(float2* s, int t)
+__device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
 {
     constexpr int T = N / 8;
     constexpr int E = 8 / R;
@@ -140,9 +140,14 @@ __device__ __forceinline__ void fft_pass(float2* s, int t)
         const int p = ib / S, q = ib % S;
         Dft<R, DIR>::run(&a[v * R]);
         if (n > R) {
-            const int base = p * (TW_N / n);
+            // W_n^(p*u) = W_N^(p*u*S) from the workgroup's LDS copy of the N-point table (p*u < n)
+            const int base = p * S;
 #pragma unroll
-            for (int u = 1; u < R; ++u) a[v * R + u] = cmul(a[v * R + u], twid<DIR>(u * base));
+            for (int u = 1; u < R; ++u) {
+                float2 w = tws[u * base];
+                if (DIR > 0) w.y = -w.y;
+                a[v * R + u] = cmul(a[v * R + u], w);
+            }
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) s[pad_idx(q + S * (R * p + u))] = a[v * R + u];
@@ -151,21 +156,28 @@ __device__ __forceinline__ void fft_pass(float2* s, int t)
 }
 
 template <int N, int S, int DIR> struct Passes {
-    static __device__ __forceinline__ void run(float2* s, int t)
+    static __device__ __forceinline__ void run(float2* s, int t, const float2* tws)
     {
         constexpr int n = N / S;
         constexpr int R = n >= 8 ? 8 : n;
-        fft_pass<N, R, S, DIR>(s, t);
-        Passes<N, S * R, DIR>::run(s, t);
+        fft_pass<N, R, S, DIR>(s, t, tws);
+        Passes<N, S * R, DIR>::run(s, t, tws);
     }
 };
 template <int N, int DIR> struct Passes<N, N, DIR> {
-    static __device__ __forceinline__ void run(float2*, int) {}
+    static __device__ __forceinline__ void run(float2*, int, const float2*) {}
 };
 
 // Caller must have issued __syncthreads() after filling `s`; on return the result is in `s`
 // (natural order) and visible to the whole workgroup.
-template <int N, int DIR> __device__ __forceinline__ void fft_lds(float2* s, int t) { Passes<N, 1, DIR>::run(s, t); }
+template <int N, int DIR> __device__ __forceinline__ void fft_lds(float2* s, int t, const float2* tws) { Passes<N, 1, DIR>::run(s, t, tws); }
+
+// Copy the N-point twiddle table W_N^k, k < N, into LDS (once per workgroup): the passes then read twiddles
+// from LDS instead of issuing 7 global loads per thread and pass through the texture path.
+template <int N, int NT> __device__ __forceinline__ void load_twiddles(float2* tws)
+{
+    for (int i = threadIdx.x; i < N; i += NT) tws[i] = g_tw[i * (TW_N / N)];
+}
 
 // ------------------------------------------------------------------------------------------
 // row pass, forward: real rows -> packed half spectra
@@ -197,6 +209,8 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     using Cfg = RowCfg<N>;
     constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
     extern __shared__ float2 s[];
+    float2* tws = s + G * PL;
+    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const int g = tid / T, t = tid % T;
     const long pair0 = (long)blockIdx.x * G;
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
         }
     }
     __syncthreads();
-    fft_lds<N, -1>(s + g * PL, t);
+    fft_lds<N, -1>(s + g * PL, t, tws);
 
     const int half = Wc / 2;
     for (int it = tid; it < G * 2 * half; it += NT) {
@@ -239,6 +253,8 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     using Cfg = RowCfg<N>;
     constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
     extern __shared__ float2 s[];
+    float2* tws = s + G * PL;
+    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const int g = tid / T, t = tid % T;
     const long pair0 = (long)blockIdx.x * G;
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
         z[pad_idx(N - k - 1)] = make_float2(a.z + b.w, -a.w + b.z);
     }
     __syncthreads();
-    fft_lds<N, +1>(s + g * PL, t);
+    fft_lds<N, +1>(s + g * PL, t, tws);
 
     constexpr int NV = G * 2 * N / 4;
     float4* dst = reinterpret_cast<float4*>(out + pair0 * 2 * N);
@@ -308,6 +324,8 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
 {
     constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
     extern __shared__ float2 s[];
+    float2* tws = s + CW * PL;
+    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const long plane = blockIdx.x;
     const int c0 = blockIdx.y * CW;
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
         s[(2 * c2 + 1) * PL + pad_idx(r)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    fft_lds<N, -1>(s + (tid / T) * PL, tid % T);
+    fft_lds<N, -1>(s + (tid / T) * PL, tid % T, tws);
 
     const int Nyrs = Wc + 1;
     float2* dst = out + plane * Nxs * (long)Nyrs;
@@ -347,6 +365,8 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
 {
     constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
     extern __shared__ float2 s[];
+    float2* tws = s + CW * PL;
+    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const long plane = blockIdx.x;
     const int c0 = blockIdx.y * CW;
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
         s[c * PL + pad_idx(r)] = z;
     }
     __syncthreads();
-    fft_lds<N, +1>(s + (tid / T) * PL, tid % T);
+    fft_lds<N, +1>(s + (tid / T) * PL, tid % T, tws);
 
     float2* dst = mid + plane * N * (long)Wc + c0;
     for (int it = tid; it < N * (CW / 2); it += NT) {
@@ -398,7 +418,7 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
 template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, long npairs, int Wc, hipStream_t st)
 {
     using Cfg = RowCfg<N>;
-    const size_t lds = sizeof(float2) * Cfg::G * Cfg::PL;
+    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL + N);
     hipError_t e = allow_lds(r2c_rows_kernel<N>, lds);
     if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
@@ -408,7 +428,7 @@ template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, lo
 template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, long npairs, int Wc, float scale, hipStream_t st)
 {
     using Cfg = RowCfg<N>;
-    const size_t lds = sizeof(float2) * Cfg::G * Cfg::PL;
+    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL + N);
     hipError_t e = allow_lds(c2r_rows_kernel<N>, lds);
     if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
@@ -417,7 +437,7 @@ template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, l
 }
 template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st)
 {
-    const size_t lds = sizeof(float2) * CW * pad_len(N);
+    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N);
     hipError_t e = allow_lds(fwd_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
     fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
@@ -425,7 +445,7 @@ template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float
 }
 template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2* mid, long planes, int Wc, int Nxi, hipStream_t st)
 {
-    const size_t lds = sizeof(float2) * CW * pad_len(N);
+    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N);
     hipError_t e = allow_lds(inv_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
     inv_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(in, mid, Wc, Nxi);

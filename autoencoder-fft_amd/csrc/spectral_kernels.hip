@@ -165,10 +165,12 @@ __device__ __forceinline__ BlockId xcd_decode(int gx, int gy, int gz)
         b.ok = b.bz < gz;
         return b;
     }
+    // bin tile slowest: the gy*gz workgroups that re-read the same A / B bins run back to back on ONE XCD, so the
+    // re-reads hit that XCD's L2 instead of going back to HBM (decisive when the tensors exceed the caches)
     const int xcd = lin & 7, slot = lin >> 3;
-    const int nbx8 = (gx + 7) >> 3;
-    b.bx = (slot % nbx8) * 8 + xcd;
-    const int rest = slot / nbx8;
+    const int per = gy * gz;
+    b.bx = (slot / per) * 8 + xcd;
+    const int rest = slot - (slot / per) * per;
     b.by = rest % gy; b.bz = rest / gy;
     b.ok = b.bx < gx && b.bz < gz;
     return b;
