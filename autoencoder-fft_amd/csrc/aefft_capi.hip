@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -268,10 +269,12 @@ static int do_contract2(aefft_ctx* ctx, const Contract& q0, const Contract& q1)
 }
 
 // conv_k over a batch: O[b][r] = sum_k (X[b][k]/R) * W[r][k] (+ bias[r]*Nx*Ny at DC)
-static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny)
+static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny,
+                   float2* Ocrop = nullptr, int Nxs = 0, int Nys = 0)
 {
     const long P = bins(Nx, Ny);
     Contract q{};
+    if (Ocrop) { q.Out2 = Ocrop; q.dnNx = Nx; q.dnNy = Ny; q.dnNxs = Nxs; q.dnNys = Nys; }
     q.A = W; q.a_r = (long)K * P; q.a_k = P;
     q.B = X; q.b_k = P; q.b_c = (long)K * P;
     q.Out = O; q.o_r = P; q.o_c = (long)R * P;
@@ -415,9 +418,11 @@ struct Momentum { float *Dc, *Df, *Db, *Dp; };
 
 // the coordinate-space part of `backprop` (fft_backproplib.cu:1229-1272) on already shrunk gradients
 static int do_update(aefft_ctx* ctx, float* c, float* f, float* b, float* p, const float* dck, const float* dfk, const float* db,
-                     const float* dp, Momentum mo, int dM, int dD, int Nk, int Nl, float del, int maxdiff, int sym, float gscale)
+                     const float* dp, Momentum mo, int dM, int dD, int Nk, int Nl, float del, int maxdiff, int sym, float gscale,
+                     float* zero = nullptr)
 {
     UpdateArgs a{};
+    a.zero = zero;
     a.c = c; a.f = f; a.b = b; a.p = p;
     a.dck = dck; a.dfk = dfk; a.db = db; a.dp = dp;
     a.Dc = mo.Dc; a.Df = mo.Df; a.Db = mo.Db; a.Dp = mo.Dp;
@@ -670,7 +675,9 @@ struct aefft_net {
     size_t mse_cap = 0;
     const float* last_frames = nullptr;
     bool have_forward = false, have_grad = false;
+    bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
     // shared scratch sized for the largest pair
+    bool fuse_crop = true;     // encoder convs also write the next pair's cropped input (no resize launches)
     bool pruned = true;        // every pair's kernel support has a pruned transform -> no shared FFT workspace in the backward
     float* real;
 };
@@ -888,8 +895,15 @@ extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* rec
     RET_IF(do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
     for (int l = 0; l < L; ++l) {
         Pair& q = n->pr[l];
-        if (l > 0 && q.s != 1) RET_IF(do_resize(ctx, n->pr[l - 1].H, q.X, (long)B * q.dD, q.Nxin, q.Nyin, q.Nx, q.Ny));
-        RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny));
+        // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
+        static const char* nofuse = getenv("AEFFT_NOFUSECROP");
+        const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !nofuse;
+        if (fuse) { const Pair& nx = n->pr[l + 1]; RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny, nx.X, nx.Nx, nx.Ny)); }
+        else RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny));
+        if (!fuse && l + 1 < L && n->pr[l + 1].s != 1) {
+            const Pair& nx = n->pr[l + 1];
+            RET_IF(do_resize(ctx, q.H, nx.X, (long)B * nx.dD, nx.Nxin, nx.Nyin, nx.Nx, nx.Ny));
+        }
     }
     // decoder (:1356-1361): conv then zero-pad up-sampling.  The up-sampled tensor is never stored: the next
     // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
@@ -957,7 +971,7 @@ static int pair_apply(aefft_net* n, Pair& q, float del, int maxdiff, int sym, fl
     float* g = n->grad + q.goff;
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
     RET_IF(do_update(ctx, q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
-                     q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale));
+                     q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->burst ? nullptr : mse_slot));
     RET_IF(pair_spectra(n, q));
     // re-forward of this pair alone (fft_backproplib.cu:1460-1461) and its MSE (:1463)
     RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, n->B, q.dM, q.dD, q.Nx, q.Ny));
@@ -986,10 +1000,14 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     const float del = 0.1f * del0;                      // :1445
     HIPCHK(ctx, hipMemsetAsync(n->mse_dev, 0, sizeof(float) * (n_iter + 1), ctx->stream));
     RET_IF(do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_dev, nullptr, n->B, q.dM, q.dD, q.Nx, q.Ny));     // :1440
-    for (int it = 0; it < n_iter; ++it) {
-        RET_IF(pair_grad(n, q));
-        RET_IF(pair_apply(n, q, del, maxdiff, sym, 1.0f, n->mse_dev + it + 1));
+    n->burst = true;
+    int rcb = AEFFT_OK;
+    for (int it = 0; it < n_iter && rcb == AEFFT_OK; ++it) {
+        rcb = pair_grad(n, q);
+        if (rcb == AEFFT_OK) rcb = pair_apply(n, q, del, maxdiff, sym, 1.0f, n->mse_dev + it + 1);
     }
+    n->burst = false;
+    RET_IF(rcb);
     n->have_grad = false;
     if (mse_h) {
         HIPCHK(ctx, hipMemcpyAsync(mse_h, n->mse_dev, sizeof(float) * (n_iter + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -1022,7 +1040,6 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
     RET_IF(aefft_net_forward(n, frames_d, recon_d));
-    HIPCHK(ctx, hipMemsetAsync(n->scratch, 0, sizeof(float) * n->scratch_n, ctx->stream));   // all MSE slots + es, once per step
     const bool side = use_side_streams(n);
     if (side) RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;

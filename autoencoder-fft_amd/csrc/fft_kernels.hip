@@ -217,17 +217,26 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
 
     constexpr int NV = G * 2 * N / 4;
     const float4* src = reinterpret_cast<const float4*>(in + pair0 * 2 * N);
-    for (int v = tid; v < NV; v += NT) {
+    // all global loads of the tile first (branch-free, clamped index), then the LDS scatter: hipcc does not hoist
+    // loads across the iterations of a load->use loop, which would serialise NV/NT memory round trips
+    constexpr int NLD = NV / NT;
+    static_assert(NV % NT == 0, "tile must be a whole number of float4 per thread");
+    const long vmax = (npairs - pair0) * (2 * N / 4) - 1;      // last valid float4 of this workgroup's chunk
+    float4 val[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) { const long v = tid + k * NT; val[k] = src[v <= vmax ? v : vmax]; }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int v = tid + k * NT;
         const int e = v * 4;
         const int gg = e / (2 * N), o = e % (2 * N);
         const int row = o / N, n0 = o % N;
         if (pair0 + gg < npairs) {
-            const float4 val = src[v];
             float* dst = reinterpret_cast<float*>(s + gg * PL) + row;
-            dst[2 * pad_idx(n0)] = val.x;
-            dst[2 * pad_idx(n0 + 1)] = val.y;
-            dst[2 * pad_idx(n0 + 2)] = val.z;
-            dst[2 * pad_idx(n0 + 3)] = val.w;
+            dst[2 * pad_idx(n0)] = val[k].x;
+            dst[2 * pad_idx(n0 + 1)] = val[k].y;
+            dst[2 * pad_idx(n0 + 2)] = val[k].z;
+            dst[2 * pad_idx(n0 + 3)] = val[k].w;
         }
     }
     __syncthreads();
@@ -260,16 +269,27 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     const long pair0 = (long)blockIdx.x * G;
 
     // Z[k] = A[k] + i*B[k], Z[N-k] = conj(A[k]) + i*conj(B[k]); k handled in pairs (k, k+1), k even < N/2
-    for (int it = tid; it < G * (N / 4); it += NT) {
+    constexpr int NIT = G * (N / 4) / NT;                       // = 2 when NT = G*N/8
+    static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of items per thread");
+    float4 av[NIT], bv[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+        const int it = tid + q * NT;
+        const int gg = it / (N / 4), k = (it % (N / 4)) * 2;
+        const bool ok = (pair0 + gg < npairs) && k < Wc;
+        const long pr = (pair0 + gg < npairs) ? pair0 + gg : npairs - 1;
+        const float2* rowA = mid + (pr * 2) * Wc + (k < Wc ? k : 0);
+        av[q] = *reinterpret_cast<const float4*>(rowA);
+        bv[q] = *reinterpret_cast<const float4*>(rowA + Wc);
+        if (!ok) { av[q] = make_float4(0.f, 0.f, 0.f, 0.f); bv[q] = av[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+        const int it = tid + q * NT;
         const int gg = it / (N / 4), k = (it % (N / 4)) * 2;
         if (pair0 + gg >= npairs) continue;
         float2* z = s + gg * PL;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (k < Wc) {
-            const float2* rowA = mid + ((pair0 + gg) * 2) * Wc;
-            a = *reinterpret_cast<const float4*>(rowA + k);
-            b = *reinterpret_cast<const float4*>(rowA + Wc + k);
-        }
+        const float4 a = av[q], b = bv[q];
         if (k == 0) {
             z[pad_idx(0)] = make_float2(a.x, b.x);          // DC of both rows (imaginary parts ignored)
             z[pad_idx(N / 2)] = make_float2(a.y, b.y);      // Nyquist, carried in .y of the packed column
@@ -331,11 +351,19 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
     const int c0 = blockIdx.y * CW;
 
     const float2* src = mid + plane * N * (long)Wc + c0;
-    for (int it = tid; it < N * (CW / 2); it += NT) {
+    constexpr int NLD = N * (CW / 2) / NT;                      // = 4 for every instantiation (NT = CW*N/8)
+    float4 val[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int it = tid + k * NT;
+        val[k] = *reinterpret_cast<const float4*>(src + (long)(it / (CW / 2)) * Wc + 2 * (it % (CW / 2)));
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int it = tid + k * NT;
         const int r = it / (CW / 2), c2 = it % (CW / 2);
-        const float4 v = *reinterpret_cast<const float4*>(src + (long)r * Wc + 2 * c2);
-        s[(2 * c2) * PL + pad_idx(r)] = make_float2(v.x, v.y);
-        s[(2 * c2 + 1) * PL + pad_idx(r)] = make_float2(v.z, v.w);
+        s[(2 * c2) * PL + pad_idx(r)] = make_float2(val[k].x, val[k].y);
+        s[(2 * c2 + 1) * PL + pad_idx(r)] = make_float2(val[k].z, val[k].w);
     }
     __syncthreads();
     fft_lds<N, -1>(s + (tid / T) * PL, tid % T, tws);

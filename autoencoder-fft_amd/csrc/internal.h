@@ -44,6 +44,9 @@ struct Contract {
     // are [upNxs][upNys/2+1] spectra that are zero-padded on the fly to the [upNx][upNy/2+1] grid of A/Out.
     // Destination bins outside the padded support only receive the bias term (everything else is 0).
     int upNx, upNy, upNxs, upNys;       // upNx == 0: no remap
+    // Fused spectral down-sampling of the OUTPUT (fft.cu:98-113): besides Out, every output bin that survives the
+    // crop from [dnNx][dnNy/2+1] to [dnNxs][dnNys/2+1] is also written to Out2 (same [r][c] plane order, small planes).
+    float2* Out2; int dnNx, dnNy, dnNxs, dnNys;   // Out2 == null: off
 };
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
@@ -79,6 +82,7 @@ struct UpdateArgs {
     float gscale;                         // gradients are multiplied by this first (1/world_size for data-parallel means)
     int sym;                              // tied weights: g = g_c[m][d] + g_f[d][m], f[d][m] <- c[m][d]
     float *ddc, *ddf, *ddb, *ddp;         // optional: record the gradients used (adapt_rate, backproplib.cu:33); may be null
+    float* zero;                          // optional: one float set to 0 (the pair's MSE accumulator, saves a memset launch)
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);                                      // fft.cu:605 / 657
 hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,

@@ -16,6 +16,7 @@
 // Row and column phase tables (Nx*Nk and Nyr*Nl complex) are built per workgroup in LDS from the
 // global twiddle table, so each bin costs one 8-byte global access plus LDS reads.
 #include "internal.h"
+#include <algorithm>
 
 namespace aefft {
 
@@ -29,101 +30,116 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
     return w;
 }
 
+// Thread <-> (plane, column j); the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} is row independent, so
+// it is formed once per thread (25 real x complex FMAs) and every output row then costs 5 complex multiplies with
+// the row phases (LDS broadcast reads).  Consecutive threads own consecutive columns: coalesced stores.
 template <int NK, int NL>
-__global__ __launch_bounds__(256) void kspec_kernel(const float* __restrict__ kern, float2* __restrict__ K,
+__global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ kern, float2* __restrict__ K,
                                                     const float2* __restrict__ tw, long planes, int Nx, int Ny,
                                                     int rows_per_chunk, int ppb)
 {
     extern __shared__ float2 lds[];
     const int Nyr = Ny / 2 + 1;
     float2* rowph = lds;                                 // [rows_per_chunk][NK]
-    float2* colph = lds + rows_per_chunk * NK;           // [Nyr][NL]
-    float* taps = reinterpret_cast<float*>(colph + Nyr * NL);   // [ppb][NK*NL]
-    const long plane0 = (long)blockIdx.x * ppb;
-    const int np = (int)min((long)ppb, planes - plane0);
     const int i0 = blockIdx.y * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
-    // the phase tables depend on (Nx, Ny) only: built once per workgroup, shared by its ppb planes
-    for (int t = threadIdx.x; t < nrows * NK; t += 256) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, 1.f);
-    for (int t = threadIdx.x; t < Nyr * NL; t += 256) colph[t] = phase(tw, t / NL, t % NL - NL / 2, Ny, 1.f);
-    for (int t = threadIdx.x; t < np * NK * NL; t += 256) taps[t] = kern[plane0 * NK * NL + t];
+    for (int t = threadIdx.x; t < nrows * NK; t += blockDim.x) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, 1.f);
     __syncthreads();
-    const int nb = nrows * Nyr;
-    for (int idx = threadIdx.x; idx < np * nb; idx += 256) {
-        const int pl = idx / nb, bin = idx - pl * nb;
-        const int i = bin / Nyr, j = bin - i * Nyr;
-        const float* c = taps + pl * NK * NL;
+    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    const long plane = (long)blockIdx.x * ppb + pl;
+    if (pl >= ppb || plane >= planes) return;
+    float2 v[NK];
+    {
+        float2 cp[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) cp[l] = phase(tw, j, l - NL / 2, Ny, 1.f);
+        const float* c = kern + plane * NK * NL;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            v[k] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) { const float w = c[k * NL + l]; v[k].x += w * cp[l].x; v[k].y += w * cp[l].y; }
+        }
+    }
+    float2* dst = K + (plane * Nx + i0) * (long)Nyr + j;
+    for (int i = 0; i < nrows; ++i) {
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            float2 v = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const float2 cp = colph[j * NL + l];
-                const float w = c[k * NL + l];
-                v.x += w * cp.x; v.y += w * cp.y;
-            }
             const float2 rp = rowph[i * NK + k];
-            acc.x += v.x * rp.x - v.y * rp.y;
-            acc.y += v.x * rp.y + v.y * rp.x;
+            acc.x += v[k].x * rp.x - v[k].y * rp.y;
+            acc.y += v[k].x * rp.y + v[k].y * rp.x;
         }
-        K[((plane0 + pl) * Nx + i0) * (long)Nyr + bin] = acc;
+        dst[(long)i * Nyr] = acc;
     }
 }
 
-// Separable evaluation on a chunk of RB rows of one plane:
-//   t[i][l]   = sum_j  w_j * D[i][j] * e^{+2 pi i j*lam_l/Ny}            (RB*NL complex values; j split in JS slices)
-//   g[k][l]  += Re sum_i t[i][l] * e^{+2 pi i i*kap_k/Nx}                 (partial over the chunk's rows)
-// No cross-lane reduction of NK*NL accumulators per thread: step 1 has one thread per (i,l,slice),
-// step 2 one thread per (k,l).  Output: part[plane][chunk][NK*NL] (summed by ksum_kernel when chunks > 1).
+// Thread <-> (plane, column j) over a chunk of RB rows:
+//   t_k[j]   = sum_i D[i][j] * e^{+2 pi i i*kap_k/Nx}                  (row phases: LDS broadcast reads; D read once, coalesced)
+//   g[k][l] += w_j * Re( t_k[j] * e^{+2 pi i j*lam_l/Ny} )              (summed over the plane's columns through LDS, fixed order)
+// Output: part[plane][chunk][NK*NL] (summed over chunks by ksum_kernel when chunks > 1).  Deterministic.
 template <int NK, int NL>
-__global__ __launch_bounds__(256) void kgrad_kernel(const float2* __restrict__ D, float* __restrict__ part,
-                                                    const float2* __restrict__ tw, int Nx, int Ny, int RB, int JS, float scale)
+__global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D, float* __restrict__ part,
+                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny, int RB, int ppb, float scale)
 {
     extern __shared__ float2 lds[];
     const int Nyr = Ny / 2 + 1;
-    float2* rows = lds;                          // [RB][Nyr]
-    float2* colph = rows + RB * Nyr;             // [Nyr][NL]  w_j * e^{+...}
-    float2* tpart = colph + Nyr * NL;            // [JS][RB*NL]
-    float2* rowph = tpart + JS * RB * NL;        // [RB][NK]   e^{+...}
-    const long plane = blockIdx.x;
+    const int nthr = blockDim.x;
+    float2* rowph = lds;                                            // [RB][NK]
+    float* contrib = reinterpret_cast<float*>(rowph + RB * NK);     // [NK*NL][nthr]
     const int chunk = blockIdx.y, nchunks = gridDim.y;
     const int i0 = chunk * RB;
-    const float2* src = D + (plane * Nx + i0) * (long)Nyr;
-    for (int t = threadIdx.x; t < RB * Nyr; t += 256) rows[t] = src[t];
-    for (int t = threadIdx.x; t < Nyr * NL; t += 256) {
-        const int j = t / NL;
-        const float2 w = phase(tw, j, t % NL - NL / 2, Ny, -1.f);
+    for (int t = threadIdx.x; t < RB * NK; t += nthr) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, -1.f);
+    __syncthreads();
+    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    const long plane = (long)blockIdx.x * ppb + pl;
+    const bool active = pl < ppb && plane < planes;
+    float2 t[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) t[k] = make_float2(0.f, 0.f);
+    if (active) {
+        const float2* src = D + (plane * Nx + i0) * (long)Nyr + j;
+        // batches of 8 rows: all 8 loads are issued before the first use (hipcc does not pipeline loads across
+        // loop iterations by itself, and this loop is otherwise one memory round trip per row)
+        int i = 0;
+        for (; i + 8 <= RB; i += 8) {
+            float2 d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = src[(long)(i + u) * Nyr];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const float2 rp = rowph[(i + u) * NK + k];
+                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
+                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
+                }
+        }
+        for (; i < RB; ++i) {
+            const float2 d = src[(long)i * Nyr];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const float2 rp = rowph[i * NK + k];
+                t[k].x += d.x * rp.x - d.y * rp.y;
+                t[k].y += d.x * rp.y + d.y * rp.x;
+            }
+        }
         const float wj = (j == 0 || j == Ny / 2) ? 1.f : 2.f;
-        colph[t] = make_float2(w.x * wj, w.y * wj);
-    }
-    for (int t = threadIdx.x; t < RB * NK; t += 256) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, -1.f);
-    __syncthreads();
-    const int nitem = RB * NL * JS;
-    for (int it = threadIdx.x; it < nitem; it += 256) {
-        const int js = it / (RB * NL), il = it % (RB * NL);
-        const int i = il / NL, l = il % NL;
-        const int per = (Nyr + JS - 1) / JS;
-        const int j0 = js * per, j1 = min(Nyr, j0 + per);
-        float2 acc = make_float2(0.f, 0.f);
-        for (int j = j0; j < j1; ++j) {
-            const float2 d = rows[i * Nyr + j], cp = colph[j * NL + l];
-            acc.x += d.x * cp.x - d.y * cp.y;
-            acc.y += d.x * cp.y + d.y * cp.x;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float2 cp = phase(tw, j, l - NL / 2, Ny, -1.f);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) contrib[(k * NL + l) * nthr + threadIdx.x] = wj * (t[k].x * cp.x - t[k].y * cp.y);
         }
-        tpart[it] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < NK * NL) {
-        const int k = threadIdx.x / NL, l = threadIdx.x % NL;
+    for (int it = threadIdx.x; it < ppb * NK * NL; it += nthr) {
+        const int p2 = it / (NK * NL), kl = it - p2 * (NK * NL);
+        const long pln = (long)blockIdx.x * ppb + p2;
+        if (pln >= planes) continue;
         float g = 0.f;
-        for (int i = 0; i < RB; ++i) {
-            float2 t = make_float2(0.f, 0.f);
-            for (int js = 0; js < JS; ++js) { const float2 p = tpart[js * RB * NL + i * NL + l]; t.x += p.x; t.y += p.y; }
-            const float2 rp = rowph[i * NK + k];
-            g += t.x * rp.x - t.y * rp.y;
-        }
-        part[(plane * nchunks + chunk) * (NK * NL) + threadIdx.x] = g * scale;
+        for (int jj = 0; jj < Nyr; ++jj) g += contrib[kl * nthr + p2 * Nyr + jj];
+        part[(pln * nchunks + chunk) * (NK * NL) + kl] = g * scale;
     }
 }
 
@@ -138,64 +154,59 @@ __global__ __launch_bounds__(256) void ksum_kernel(const float* __restrict__ par
     g[e] = s;
 }
 
-static size_t kspec_lds(int rows, int Ny, int Nk, int Nl, int ppb) { return sizeof(float2) * ((size_t)rows * Nk + (size_t)(Ny / 2 + 1) * Nl) + sizeof(float) * Nk * Nl * ppb; }
-// rows per workgroup: as many as fit ~32 KB of LDS, fewer when that would leave the chip short of workgroups
-static void kgrad_geom(long planes, int Nx, int Ny, int Nl, int* RB, int* JS)
+static size_t kspec_lds(int rows, int Nk) { return sizeof(float2) * (size_t)rows * Nk; }
+// planes per workgroup (one thread per column) and rows per workgroup (>= 8, fewer when that would leave the
+// chip short of workgroups)
+static void kgrad_geom(long planes, int Nx, int Ny, int* RB, int* ppb, int* threads)
 {
     const int Nyr = Ny / 2 + 1;
-    int rb = 1;
-    while (rb * 2 <= Nx && (size_t)rb * 2 * Nyr * sizeof(float2) <= 32 * 1024) rb *= 2;
-    while (rb > 1 && planes * (Nx / rb) < 512) rb /= 2;
-    int js = 256 / (rb * Nl);
-    if (js < 1) js = 1;
-    if (js > Nyr) js = Nyr;
-    *RB = rb; *JS = js;
+    *ppb = std::max(1, 256 / Nyr);
+    *threads = ((*ppb * Nyr + 63) / 64) * 64;
+    const long pblocks = (planes + *ppb - 1) / *ppb;
+    int chunks = 1;       // row chunks cost a second (ksum) launch: only when one workgroup per plane group would starve the chip
+    if (pblocks < 96) while (pblocks * chunks < 256 && Nx / (chunks * 2) >= 16) chunks *= 2;
+    *RB = Nx / chunks;
 }
 static size_t kgrad_lds(long planes, int Nx, int Ny, int Nk, int Nl)
 {
-    int RB, JS;
-    kgrad_geom(planes, Nx, Ny, Nl, &RB, &JS);
-    const int Nyr = Ny / 2 + 1;
-    return sizeof(float2) * ((size_t)RB * Nyr + (size_t)Nyr * Nl + (size_t)JS * RB * Nl + (size_t)RB * Nk);
+    int RB, ppb, thr;
+    kgrad_geom(planes, Nx, Ny, &RB, &ppb, &thr);
+    return sizeof(float2) * (size_t)RB * Nk + sizeof(float) * (size_t)Nk * Nl * thr;
 }
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl)
 {
-    int RB, JS;
-    kgrad_geom(planes, Nx, Ny, Nl, &RB, &JS);
+    int RB, ppb, thr;
+    kgrad_geom(planes, Nx, Ny, &RB, &ppb, &thr);
     return (size_t)planes * (Nx / RB) * Nk * Nl;
 }
 
 bool pruned_supported(int Nk, int Nl, int Nx, int Ny)
 {
     if (!((Nk == 3 && Nl == 3) || (Nk == 5 && Nl == 5) || (Nk == 7 && Nl == 7))) return false;
-    if (Nx > TW_N || Ny > TW_N || (TW_N % Nx) || (TW_N % Ny)) return false;
+    if (Nx > TW_N || Ny > TW_N || (TW_N % Nx) || (TW_N % Ny) || Ny / 2 + 1 > 320) return false;
     return kgrad_lds(1, Nx, Ny, Nk, Nl) <= 150 * 1024 && kgrad_lds(1L << 20, Nx, Ny, Nk, Nl) <= 150 * 1024;
 }
 
 template <int NK, int NL>
 static hipError_t run_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, hipStream_t st)
 {
-    // ~2048 bins of output per workgroup: small planes are grouped (shared phase tables), large planes are
-    // split into row chunks; at least ~1024 workgroups when the problem allows it
     const int Nyr = Ny / 2 + 1;
-    int chunks = 1, ppb = 1;
-    while ((long)(Nx / chunks) * Nyr > 2048 && Nx / (chunks * 2) >= 1) chunks *= 2;
-    while (chunks == 1 && (long)ppb * 2 * Nx * Nyr <= 2048 && planes / (ppb * 2) >= 1024) ppb *= 2;
+    if (Nyr > 320) return hipErrorInvalidValue;          // one thread per column (callers fall back to pad + R2C above 512)
+    const int ppb = std::max(1, 256 / Nyr);              // planes per workgroup
+    const int threads = ((ppb * Nyr + 63) / 64) * 64;
+    const long pblocks = (planes + ppb - 1) / ppb;
+    int chunks = 1;                                       // split the rows until the chip has ~1024 workgroups (>= 8 rows each)
+    while (pblocks * chunks < 1024 && Nx / (chunks * 2) >= 8) chunks *= 2;
     const int rows = (Nx + chunks - 1) / chunks;
-    const size_t lds = kspec_lds(rows, Ny, NK, NL, ppb);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_kernel<NK, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    kspec_kernel<NK, NL><<<dim3((unsigned)((planes + ppb - 1) / ppb), chunks), 256, lds, st>>>(k, K, tw, planes, Nx, Ny, rows, ppb);
+    kspec_kernel<NK, NL><<<dim3((unsigned)pblocks, chunks), threads, kspec_lds(rows, NK), st>>>(k, K, tw, planes, Nx, Ny, rows, ppb);
     return hipGetLastError();
 }
 
 template <int NK, int NL>
 static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2* tw, long planes, int Nx, int Ny, float scale, hipStream_t st)
 {
-    int RB, JS;
-    kgrad_geom(planes, Nx, Ny, NL, &RB, &JS);
+    int RB, ppb, thr;
+    kgrad_geom(planes, Nx, Ny, &RB, &ppb, &thr);
     const int chunks = Nx / RB;
     const size_t lds = kgrad_lds(planes, Nx, Ny, NK, NL);
     if (lds > 64 * 1024) {
@@ -203,7 +214,7 @@ static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2
         if (e != hipSuccess) return e;
     }
     float* dst = chunks == 1 ? g : part;
-    kgrad_kernel<NK, NL><<<dim3((unsigned)planes, chunks), 256, lds, st>>>(D, dst, tw, Nx, Ny, RB, JS, scale);
+    kgrad_kernel<NK, NL><<<dim3((unsigned)((planes + ppb - 1) / ppb), chunks), thr, lds, st>>>(D, dst, tw, planes, Nx, Ny, RB, ppb, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || chunks == 1) return e;
     const long n = planes * NK * NL;

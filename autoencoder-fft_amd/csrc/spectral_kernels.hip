@@ -29,6 +29,20 @@ __device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b)
     acc.y += a.x * b.y + a.y * b.x;
 }
 
+// destination bin of source bin (i, j) under the spectral crop [Nx][Ny/2+1] -> [Nxs][Nys/2+1] (inverse of fft.cu:102-111), or -1
+__device__ __forceinline__ long crop_dest(long bin, int Nx, int Ny, int Nxs, int Nys)
+{
+    const int Nyr = Ny / 2 + 1, Nyrs = Nys / 2 + 1;
+    const int i = (int)(bin / Nyr), j = (int)(bin - (long)i * Nyr);
+    int di = -1, dj = -1;
+    if (i < Nxs / 2) di = i;
+    else if (i == Nx / 2) di = Nxs / 2;
+    else if (i > Nx - Nxs / 2) di = i - Nx + Nxs;
+    if (j < Nyrs - 1) dj = j;
+    else if (j == Nyr - 1) dj = Nyrs - 1;
+    return (di >= 0 && dj >= 0) ? (long)di * Nyrs + dj : -1;
+}
+
 // Thread layout: threadIdx.x = 64 consecutive bin groups (VEC bins each: one float2 or float4 per
 // load, so a wave reads 512 B / 1 KiB contiguous), threadIdx.y = up to 4 row tiles that share
 // the B operand through L1.  Each thread owns a TR x TC register tile of outputs.
@@ -131,6 +145,10 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
         }
     }
     V* Op = reinterpret_cast<V*>(q.Out);
+    long cdst[VEC];                      // fused down-sampling: destination bin of each of this thread's bins (or -1)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cdst[v] = (q.Out2 && grp * VEC + v < q.P) ? crop_dest(grp * VEC + v, q.dnNx, q.dnNy, q.dnNxs, q.dnNys) : -1;
+    const long Ps = (long)q.dnNxs * (q.dnNys / 2 + 1);
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -145,6 +163,12 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
                 of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
             }
             Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
+            if (q.Out2) {
+                const long plane = ((r0 + i) * q.o_r + (c0 + j) * q.o_c) / q.P;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (cdst[v] >= 0) q.Out2[plane * Ps + cdst[v]] = make_float2(of[2 * v], of[2 * v + 1]);
+            }
         }
 }
 
@@ -364,6 +388,11 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
     const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
     const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
     V* Op = reinterpret_cast<V*>(q.Out);
+    long cdst[VEC];                      // fused down-sampling: destination bin of each of this thread's bins (or -1), computed once
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cdst[v] = (q.Out2 && grp * VEC + v < q.P) ? crop_dest(grp * VEC + v, q.dnNx, q.dnNy, q.dnNxs, q.dnNys) : -1;
+    const long Ps = (long)q.dnNxs * (q.dnNys / 2 + 1);
+    const long orp = q.Out2 ? q.o_r / q.P : 0, ocp = q.Out2 ? q.o_c / q.P : 0;
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -378,6 +407,13 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
                 of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
             }
             Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
+            if (q.Out2) {
+                // Out2 keeps Out's [c][r] plane order with the small plane size: plane index = ((c)*o_c + (r)*o_r) / P
+                const long plane = (long)(r0 + i) * orp + (long)(c0 + j) * ocp;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (cdst[v] >= 0) q.Out2[plane * Ps + cdst[v]] = make_float2(of[2 * v], of[2 * v + 1]);
+            }
         }
 }
 
@@ -424,6 +460,7 @@ static int contract_fast_class(const Contract2& qq)
         return a < 4.0e9 && b < 4.0e9;
     };
     for (int p = 0; p < qq.n; ++p) if (!fits32(qq.q[p]) || (!qq.q[p].biasAfterFirst && qq.q[p].bias)) return -1;
+    if (qq.q[0].Out2 && (qq.n != 1 || qq.q[0].conjA || qq.q[0].conjB || qq.q[0].A2)) return -1;
     const Contract& a = qq.q[0];
     if (qq.n == 1) {
         if (!a.conjA && !a.conjB && !a.A2) return 0;
@@ -560,6 +597,10 @@ __device__ __forceinline__ void contract_lds_body(const Contract& q, int bx, int
             if (q.bias && bin == 0) val.x += q.bias[r] * q.biasScale;
             val.x *= omul; val.y *= omul;
             q.Out[r * q.o_r + c * q.o_c + bin] = val;
+            if (q.Out2) {
+                const long db = crop_dest(bin, q.dnNx, q.dnNy, q.dnNxs, q.dnNys);
+                if (db >= 0) q.Out2[((r * q.o_r + c * q.o_c) / q.P) * ((long)q.dnNxs * (q.dnNys / 2 + 1)) + db] = val;
+            }
         }
 }
 
@@ -720,19 +761,33 @@ __global__ __launch_bounds__(256) void diff_mse_kernel(const float4* __restrict_
 {
     float part = 0.f;
     const I hp = P / 2;                                  // float4 pairs per plane
-    for (I idx = (I)blockIdx.x * 256 + threadIdx.x; idx < npairs; idx += (I)gridDim.x * 256) {
-        const float4 t = T[idx], o = O[idx];
-        const float4 e = make_float4(o.x - t.x, o.y - t.y, o.z - t.z, o.w - t.w);
-        if (E) E[idx] = e;
-        const I plane = idx / hp;
-        const unsigned bin = (unsigned)(idx - plane * hp) * 2u;
-        if (es && bin == 0) {
-            const int d = (int)(plane % (I)ch);
-            atomicAdd(&es[2 * d], e.x); atomicAdd(&es[2 * d + 1], e.y);
+    // four float4 pairs per thread and trip: 8 loads in flight before the first use
+    const I stride = (I)gridDim.x * 256;
+    for (I idx0 = (I)blockIdx.x * 256 + threadIdx.x; idx0 < npairs; idx0 += 4 * stride) {
+        float4 tv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const I idx = idx0 + u * stride;
+            const I ci = idx < npairs ? idx : npairs - 1;
+            tv[u] = T[ci]; ov[u] = O[ci];
         }
-        const unsigned j0 = bin % (unsigned)Nyr, j1 = (j0 + 1 == (unsigned)Nyr) ? 0u : j0 + 1;
-        const float n0 = (j0 > 0 && j0 < (unsigned)Nyr - 1) ? nfull / 2 : nfull, n1 = (j1 > 0 && j1 < (unsigned)Nyr - 1) ? nfull / 2 : nfull;
-        part += (e.x * e.x + e.y * e.y) / n0 + (e.z * e.z + e.w * e.w) / n1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const I idx = idx0 + u * stride;
+            if (idx >= npairs) break;
+            const float4 t = tv[u], o = ov[u];
+            const float4 e = make_float4(o.x - t.x, o.y - t.y, o.z - t.z, o.w - t.w);
+            if (E) E[idx] = e;
+            const I plane = idx / hp;
+            const unsigned bin = (unsigned)(idx - plane * hp) * 2u;
+            if (es && bin == 0) {
+                const int d = (int)(plane % (I)ch);
+                atomicAdd(&es[2 * d], e.x); atomicAdd(&es[2 * d + 1], e.y);
+            }
+            const unsigned j0 = bin % (unsigned)Nyr, j1 = (j0 + 1 == (unsigned)Nyr) ? 0u : j0 + 1;
+            const float n0 = (j0 > 0 && j0 < (unsigned)Nyr - 1) ? nfull / 2 : nfull, n1 = (j1 > 0 && j1 < (unsigned)Nyr - 1) ? nfull / 2 : nfull;
+            part += (e.x * e.x + e.y * e.y) / n0 + (e.z * e.z + e.w * e.w) / n1;
+        }
     }
     if (!mse_acc) return;
 #pragma unroll

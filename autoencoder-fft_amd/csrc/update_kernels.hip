@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a)
 {
     const int n = a.dM * a.dD * a.Nk * a.Nl;
     const int idk = blockIdx.x * 256 + threadIdx.x;
+    if (idk == 0 && a.zero) *a.zero = 0.f;
     if (idk >= n) return;
     const bool multi = a.cd != nullptr;
     if (!a.sym) {
