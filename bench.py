@@ -29,6 +29,25 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# kernel id (aefft_prof_name) -> kernel family in the rocprofv3 --pmc summaries under profiles/
+PMC_FAMILY = {"contract": ["contract_fast_kernel", "contract_kernel", "contract_lds_kernel"], "r2c_rows": ["r2c_rows_kernel"],
+              "r2c_cols": ["fwd_cols_kernel"], "c2r_cols": ["inv_cols_kernel"], "c2r_rows": ["c2r_rows_kernel"],
+              "kgrad": ["kgrad_kernel"], "kspec": ["kspec_kernel"], "diff_mse": ["diff_mse_kernel"]}
+
+
+def pmc_traffic(variant, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note; tools_pmc.py).  None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_cfg3{variant}.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    n = b = 0
+    for fam in PMC_FAMILY.get(kernel, []):
+        if fam in d:
+            n += d[fam]["launches"]; b += d[fam]["hbm_bytes_per_launch"] * d[fam]["launches"]
+    return b / n if n else None
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -170,7 +189,7 @@ def main():
         avg_s = dom["ms"] / dom["launches"] * 1e-3
         ach = per_launch_bytes / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 3,
+                "traffic": pmc_traffic(a.variant, name) if (a.size == 512 and a.batch == 32) else None, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 3,
                 "algo_bytes_per_launch": per_launch_bytes, "share_of_kernel_time": dom["ms"] / tot,
                 "kernels": {k: {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] / 3,
                                 "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0}

@@ -411,3 +411,23 @@ def batch_train_iter(Xs, Ts, Os, C, F, c, f, b, p, mom, dele, maxdiff=0, dtype=n
     mse = dtype(np.mean([mse_fft(T, O, dM, dD, Nx, Ny, dtype) for T, O in zip(Ts, Os2)]))
     return dict(c=c, f=f, b=b, p=p, C=C, F=F, mom=(Dc, Df, Db, Dp), Hs=Hs, Os=Os2, mse=mse,
                 grads=(dck, dfk, db, dp))
+
+
+# ----------------------------------------------------------------------------------------
+# build-defined tied-weight update for FFT mode (the reference has tied weights
+# only in spatial mode, backproplib.cu:521-644, whose rule is mirrored): g = (g_c[m][d] + g_f[d][m]) / 2
+# (i.e. the sum with Norm doubled, :533), biases' gradients halved likewise, c <- c - D, f[d][m] <- c[m][d].
+# ----------------------------------------------------------------------------------------
+def backprop_sym(c, f, b, p, dck, dfk, db, dp, Dc, Df, Db, Dp, dele, cd=None, fd=None, bd=None, pd=None, dtype=np.float64):
+    dele = dtype(dele)
+    g = 0.5 * (dck + np.transpose(dfk, (1, 0, 2, 3)))
+    gb, gp = 0.5 * db, 0.5 * dp
+    if cd is not None:
+        g = dtype(W0) * g - dtype(W1) * 0.5 * (cd + np.transpose(fd, (1, 0, 2, 3)))
+        gb = dtype(W0) * gb - dtype(W1) * bd
+        gp = dtype(W0) * gp - dtype(W1) * pd
+    Dc = _clip_step(g, Dc, dele, dtype); c = (c - Dc).astype(dtype)
+    f = np.transpose(c, (1, 0, 2, 3)).copy()
+    Db = _clip_step(gb, Db, dele, dtype); b = (b - Db).astype(dtype)
+    Dp = _clip_step(gp, Dp, dele, dtype); p = (p - Dp).astype(dtype)
+    return c, f, b, p, Dc, Df, Db, Dp
