@@ -268,21 +268,109 @@ static int do_contract2(aefft_ctx* ctx, const Contract& q0, const Contract& q1)
     return AEFFT_OK;
 }
 
-// conv_k over a batch: O[b][r] = sum_k (X[b][k]/R) * W[r][k] (+ bias[r]*Nx*Ny at DC)
-static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny,
-                   float2* Ocrop = nullptr, int Nxs = 0, int Nys = 0)
+// ---- contraction descriptors (shared by the single-problem and the grouped launches) ----
+static Contract mk_conv(const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny)
 {
     const long P = bins(Nx, Ny);
     Contract q{};
-    if (Ocrop) { q.Out2 = Ocrop; q.dnNx = Nx; q.dnNy = Ny; q.dnNxs = Nxs; q.dnNys = Nys; }
     q.A = W; q.a_r = (long)K * P; q.a_k = P;
     q.B = X; q.b_k = P; q.b_c = (long)K * P;
     q.Out = O; q.o_r = P; q.o_c = (long)R * P;
     q.R = R; q.C = B; q.K = K; q.P = P;
-    q.conjA = q.conjB = false;
     q.preDivB = (float)R;                       // in_t /= dM   (fft_backproplib.cu:176-177)
-    q.postDiv = 0.f;
     q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
+    return q;
+}
+static float grad_norm(int dM, int dD, int Nx, int Ny)
+{
+    const float norm = (float)Nx * (float)Ny;                 // fft_backproplib.cu:398
+    return norm * 2 * dM * dD * Nx * Ny;                      // :399 (float arithmetic, left to right)
+}
+static Contract mk_S(const float2* Xin, const float2* T, const float2* O, float2* S, int B, int dD, long P)
+{
+    Contract q{};
+    q.A = O; q.A2 = T; q.a_r = P; q.a_k = (long)dD * P;
+    q.B = Xin; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
+    q.Out = S; q.o_r = (long)dD * P; q.o_c = P;
+    q.R = dD; q.C = dD; q.K = B; q.P = P;
+    return q;
+}
+static Contract mk_dc(const float2* F, const float2* S, float2* dc, int B, int dM, int dD, long P, float Norm)
+{
+    Contract q{};
+    q.A = F; q.a_r = P; q.a_k = (long)dM * P; q.conjA = true;
+    q.B = S; q.b_k = (long)dD * P; q.b_c = P;
+    q.Out = dc; q.o_r = (long)dD * P; q.o_c = P;
+    q.R = dM; q.C = dD; q.K = dD; q.P = P;
+    q.postDiv = Norm * (float)B;
+    return q;
+}
+static Contract mk_df(const float2* C, const float2* S, float2* df, int B, int dM, int dD, long P, float Norm)
+{
+    Contract r{};
+    r.A = S; r.a_r = (long)dD * P; r.a_k = P;
+    r.B = C; r.b_k = P; r.b_c = (long)dD * P; r.conjB = true;
+    r.Out = df; r.o_r = (long)dM * P; r.o_c = P;
+    r.R = dD; r.C = dM; r.K = dD; r.P = P;
+    r.postDiv = Norm * (float)B;
+    return r;
+}
+// Re-forward of one pair for its MSE only (fft_backproplib.cu:1460-1463 when nothing else consumes H and O): the two
+// conv_k collapse per bin into G[d'][d] = sum_m F[d'][m] C[m][d] / (dM*dD) (no batch dimension) ...
+static Contract mk_G(const float2* F, const float2* C, float2* G, int dM, int dD, long P)
+{
+    Contract q{};
+    q.A = F; q.a_r = (long)dM * P; q.a_k = P;
+    q.B = C; q.b_k = (long)dD * P; q.b_c = P;
+    q.Out = G; q.o_r = (long)dD * P; q.o_c = P;
+    q.R = dD; q.C = dD; q.K = dM; q.P = P;
+    q.postDiv = (float)dM * (float)dD;
+    return q;
+}
+// ... and O_b = G X_b (+ the bias terms at DC) is compared with X_b inside the contraction's epilogue: H and O never exist.
+static Contract mk_gmse(const float2* G, const float2* X, const float2* F, const float* b, const float* p, float* mse_slot,
+                        int B, int dM, int dD, int Nx, int Ny)
+{
+    const long P = bins(Nx, Ny);
+    Contract q{};
+    q.A = G; q.a_r = (long)dD * P; q.a_k = P;
+    q.B = X; q.b_k = P; q.b_c = (long)dD * P;
+    q.R = dD; q.C = B; q.K = dD; q.P = P;
+    q.mse.acc = mse_slot; q.mse.F = F; q.mse.b = b; q.mse.p = p; q.mse.dM = dM; q.mse.Nyr = Ny / 2 + 1;
+    q.mse.nfull = (float)dD * Nx * Ny;
+    q.mse.scale = 1.0f / ((float)(2 * dM) * (float)Nx * (float)Ny * (float)B);        // as do_diff_mse
+    q.mse.norm = (float)Nx * (float)Ny;
+    return q;
+}
+static int do_contract(aefft_ctx* ctx, const Contract& q);
+// n independent contractions of class cls (see ContractN) in one launch; falls back to one launch each
+static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, int cls)
+{
+    static const char* nogroup = getenv("AEFFT_NOGROUP");
+    if (n <= 8 && n > 1 && !nogroup) {
+        ContractN g{};
+        double bytes = 0;
+        for (int i = 0; i < n; ++i) { g.q[i] = qs[i]; bytes += ((double)qs[i].R * qs[i].K + (double)qs[i].K * qs[i].C + (double)qs[i].R * qs[i].C) * qs[i].P * 8.0 * (qs[i].A2 ? 1.0 : 1.0); }
+        g.n = n; g.nA = nA;
+        hipError_t e;
+        {
+            Bracket br(ctx, KID_CONTRACT, bytes);
+            e = launch_contract_group(g, cls, ctx->cur);
+        }
+        if (e == hipSuccess) return AEFFT_OK;
+        if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(group)", e);
+        (void)hipGetLastError();
+    }
+    for (int i = 0; i < n; ++i) RET_IF(do_contract(ctx, qs[i]));
+    return AEFFT_OK;
+}
+
+// conv_k over a batch: O[b][r] = sum_k (X[b][k]/R) * W[r][k] (+ bias[r]*Nx*Ny at DC)
+static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny,
+                   float2* Ocrop = nullptr, int Nxs = 0, int Nys = 0)
+{
+    Contract q = mk_conv(X, W, bias, O, B, R, K, Nx, Ny);
+    if (Ocrop) { q.Out2 = Ocrop; q.dnNx = Nx; q.dnNy = Ny; q.dnNxs = Nxs; q.dnNys = Nys; }
     return do_contract(ctx, q);
 }
 
@@ -348,29 +436,9 @@ static int do_gradient(aefft_ctx* ctx, const float2* Xin, const float2* T, const
 {
     const long P = bins(Nx, Ny);
     const float norm = (float)Nx * (float)Ny;                 // fft_backproplib.cu:398
-    const float Norm = norm * 2 * dM * dD * Nx * Ny;          // :399 (float arithmetic, left to right)
-    {
-        Contract q{};
-        q.A = O; q.A2 = T; q.a_r = P; q.a_k = (long)dD * P;
-        q.B = Xin; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
-        q.Out = S; q.o_r = (long)dD * P; q.o_c = P;
-        q.R = dD; q.C = dD; q.K = B; q.P = P;
-        RET_IF(do_contract(ctx, q));
-    }
-    {
-        Contract q{}, r{};
-        q.A = F; q.a_r = P; q.a_k = (long)dM * P; q.conjA = true;
-        q.B = S; q.b_k = (long)dD * P; q.b_c = P;
-        q.Out = dc; q.o_r = (long)dD * P; q.o_c = P;
-        q.R = dM; q.C = dD; q.K = dD; q.P = P;
-        q.postDiv = Norm * (float)B;
-        r.A = S; r.a_r = (long)dD * P; r.a_k = P;
-        r.B = C; r.b_k = P; r.b_c = (long)dD * P; r.conjB = true;
-        r.Out = df; r.o_r = (long)dM * P; r.o_c = P;
-        r.R = dD; r.C = dM; r.K = dD; r.P = P;
-        r.postDiv = Norm * (float)B;
-        RET_IF(do_contract2(ctx, q, r));
-    }
+    const float Norm = grad_norm(dM, dD, Nx, Ny);
+    RET_IF(do_contract(ctx, mk_S(Xin, T, O, S, B, dD, P)));
+    RET_IF(do_contract2(ctx, mk_dc(F, S, dc, B, dM, dD, P, Norm), mk_df(C, S, df, B, dM, dD, P, Norm)));
     {
         Bracket br(ctx, KID_BIASGRAD, ((double)(dM * dD + dM + dD) + 2.0 * B * dD) * 8.0);
         hipError_t e = launch_bias_grad(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, ctx->cur);
@@ -671,6 +739,7 @@ struct aefft_net {
     size_t scratch_n = 0;
     float* mse_pre = nullptr;  // = scratch
     float* mse_post = nullptr; // = scratch + L
+    float* mse_slots = nullptr; // [L][MSE_SLOTS*MSE_SLOT_STRIDE] accumulators of the fused re-forward MSE (zero between uses)
     float* mse_dev = nullptr;  // scratch for bursts
     size_t mse_cap = 0;
     const float* last_frames = nullptr;
@@ -756,6 +825,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             (rc = ws_get(ctx, WS_DEN, sizeof(float) * maxDen, &dummy)) == AEFFT_OK &&
             (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->real, n->pruned ? 64 : maxReal)) == AEFFT_OK &&
+            (rc = net_alloc_t(n, &n->mse_slots, (size_t)n->L * MSE_SLOTS * MSE_SLOT_STRIDE)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->grad, goff)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
             n->scratch_n = soff; n->mse_pre = n->scratch; n->mse_post = n->scratch + n->L;
             for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
@@ -764,7 +834,8 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         }
     }
     if (rc != AEFFT_OK) { aefft_net_destroy(n); return rc; }
-    hipError_t e = hipSuccess;
+    hipError_t e = hipMemsetAsync(n->mse_slots, 0, sizeof(float) * n->L * MSE_SLOTS * MSE_SLOT_STRIDE, ctx->stream);
+    if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset(mse slots)", e); }
     for (auto& q : n->pr) {
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
         e = hipMemsetAsync(q.c, 0, nk * 4, ctx->stream); if (e) break;
@@ -1035,13 +1106,97 @@ static int join_streams(aefft_ctx* ctx)
 }
 static bool use_side_streams(const aefft_net* n) { return n->ctx->concurrency && n->pruned && n->L > 1 && n->ctx->aux[0] != nullptr; }
 
+// Step mode runs the same per-pair sequences as pair_grad / pair_apply, phase by phase over ALL pairs, so that
+// the independent contractions of a phase (4 x S, 4 x dc + 4 x df, 4 + 4 re-forward convs) go out as one launch each.
+static int bias_and_kgrad(aefft_net* n, Pair& q)
+{
+    aefft_ctx* ctx = n->ctx;
+    float* g = n->grad + q.goff;
+    const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    const float norm = (float)q.Nx * (float)q.Ny, Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+    {
+        Bracket br(ctx, KID_BIASGRAD, ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0);
+        hipError_t e = launch_bias_grad(q.O, q.X, q.F, q.b, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P, norm, Norm, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "bias_grad", e);
+    }
+    const long planes = (long)q.dM * q.dD;
+    if (q.part) return do_c2r_shrink(ctx, q.dc, g, nullptr, q.part, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl);
+    RET_IF(do_c2r_shrink(ctx, q.dc, g, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+    return do_c2r_shrink(ctx, q.df, g + nk, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl);
+}
+
+static int grads_grouped(aefft_net* n)
+{
+    aefft_ctx* ctx = n->ctx;
+    Contract qs[8];
+    for (int l0 = 0; l0 < n->L; l0 += 4) {
+        const int m = std::min(4, n->L - l0);
+        for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_S(q.X, q.X, q.O, q.S, n->B, q.dD, q.P); }
+        RET_IF(do_contract_group(ctx, qs, m, m, 1));
+    }
+    // dc | df: one dual launch per pair (the shapes differ too much across pairs for one tile configuration)
+    for (int l = n->L - 1; l >= 0; --l) {
+        Pair& q = n->pr[l];
+        const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+        RET_IF(do_contract2(ctx, mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm), mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm)));
+    }
+    for (int l = 0; l < n->L; ++l) RET_IF(bias_and_kgrad(n, n->pr[l]));
+    return AEFFT_OK;
+}
+
+// post-update MSE of pair q on the current frames (fft_backproplib.cu:1460-1463).  Step mode never reads the
+// re-forward's H and O again (the next forward overwrites them), so they are not materialised: G = F.C per bin
+// (into the dead S workspace), then one pass over X with the MSE epilogue.  Falls back to conv, conv, diff_mse
+// for shapes the lean kernel does not serve (dD == 1 or B == 1).
+static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
+{
+    aefft_ctx* ctx = n->ctx;
+    static const char* nofuse = getenv("AEFFT_NOFUSEMSE");
+    if (!nofuse && q.dD >= 2 && n->B >= 2) {
+        RET_IF(do_contract(ctx, mk_G(q.F, q.C, q.S, q.dM, q.dD, q.P)));
+        const Contract m = mk_gmse(q.S, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
+        hipError_t e;
+        {
+            Bracket br(ctx, KID_CONTRACT, ((double)m.R * m.K + 2.0 * m.K * m.C) * m.P * 8.0);
+            e = launch_contract(m, ctx->cur);
+        }
+        if (e == hipSuccess) return AEFFT_OK;
+        if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(mse)", e);
+        (void)hipGetLastError();
+    }
+    RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, n->B, q.dM, q.dD, q.Nx, q.Ny));   // :1460
+    RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, n->B, q.dD, q.dM, q.Nx, q.Ny));   // :1461
+    return do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_post + (&q - n->pr.data()), nullptr, n->B, q.dM, q.dD, q.Nx, q.Ny);   // :1463
+}
+
+static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gscale, float* mse_d)
+{
+    aefft_ctx* ctx = n->ctx;
+    for (int l = 0; l < n->L; ++l) {
+        Pair& q = n->pr[l];
+        float* g = n->grad + q.goff;
+        const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+        RET_IF(do_update(ctx, q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
+                         q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->mse_post + l));
+        RET_IF(pair_spectra(n, q));
+    }
+    for (int l = 0; l < n->L; ++l) RET_IF(reforward_mse(n, n->pr[l], n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE));
+    {
+        Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur);     // also the copy-out to mse_d
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
+    }
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* recon_d)
 {
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
     RET_IF(aefft_net_forward(n, frames_d, recon_d));
     const bool side = use_side_streams(n);
-    if (side) RET_IF(fork_streams(ctx));
+    if (!side) { RET_IF(grads_grouped(n)); n->have_grad = true; return AEFFT_OK; }
+    RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;
     for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {     // small (launch-bound) pairs first, the big ones fill in
         if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
@@ -1068,7 +1223,12 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     if (!n->have_grad) return fail(ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
     const float del = 0.1f * del0;
     const bool side = use_side_streams(n) && !maxdiff;        // the multiobjective path shares context workspaces
-    if (side) RET_IF(fork_streams(ctx));
+    if (!side) {
+        RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
+        n->have_grad = false;
+        return AEFFT_OK;
+    }
+    RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;
     for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {
         if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];

@@ -47,9 +47,21 @@ struct Contract {
     // Fused spectral down-sampling of the OUTPUT (fft.cu:98-113): besides Out, every output bin that survives the
     // crop from [dnNx][dnNy/2+1] to [dnNxs][dnNys/2+1] is also written to Out2 (same [r][c] plane order, small planes).
     float2* Out2; int dnNx, dnNy, dnNxs, dnNys;   // Out2 == null: off
+    // MSE epilogue instead of a store (mse.acc != null; needs R == K): with A = G[d'][d] = (F.C)/(dM*dD) of one pair and
+    // B = X (the pair's input spectra) the tile holds the pair-local reconstruction O_b[d'] = sum_d G[d'][d] X_b[d] + beta[d']
+    // at the DC bin (beta = Nx*Ny*(p[d'] + sum_m F[d'][m](0,0) b[m] / dD): the two bias terms of conv_k o conv_k,
+    // fft.cu:183-184), and *mse.acc += scale * sum |X_b[d'] - O_b[d']|^2 / n_bin   (mse_fft, fft.cu:480-498,1188-1190).
+    // mse.acc -> MSE_SLOTS accumulators, MSE_SLOT_STRIDE floats apart (zero before the first use; launch_mse_finish sums and clears them).
+    struct Mse { float* acc; const float2* F; const float* b; const float* p; int dM, Nyr; float nfull, scale, norm; } mse;
 };
+enum { MSE_SLOTS = 256, MSE_SLOT_STRIDE = 16 };
+hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st);
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
+// Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):
+// cls 0 = plain conv_k, 1 = S (a*conj(b), fused subtraction), 2 = first nA problems conj(a)*b (dc), the rest a*conj(b) (df).
+struct ContractN { Contract q[8]; int n, nA; int gx[8], gy[8], gz[8], start[9]; };
+hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st);
 hipError_t launch_contract(const Contract& q, hipStream_t st);
 
 hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st);

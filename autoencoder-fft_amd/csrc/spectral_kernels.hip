@@ -264,7 +264,7 @@ template <bool CA, bool CB> __device__ __forceinline__ void cfma_s(float2& acc, 
     else { acc.x = fmaf(ax, bx, acc.x); acc.x = fmaf(-ay, by, acc.x); acc.y = fmaf(ax, by, acc.y); acc.y = fmaf(ay, bx, acc.y); }
 }
 
-template <int VEC, int TR, int TC, bool CA, bool CB, bool DIFF, int KS>
+template <int VEC, int TR, int TC, bool CA, bool CB, bool DIFF, int KS, bool MSE = false>
 __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, int by, int zblk, float* red)
 {
     using L = BufLoad<VEC>;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
     const int ks = KS > 1 ? threadIdx.y : 0;
     const int r0 = (KS > 1 ? by : by * blockDim.y + threadIdx.y) * TR, c0 = zblk * TC;
     const bool inside = grp * VEC < q.P && r0 < q.R && c0 < q.C;
-    if (KS == 1 && !inside) return;
+    if (KS == 1 && !inside && !MSE) return;             // (the MSE epilogue ends in a workgroup reduction)
     long bgrp = grp;
     bool live = inside;
     if (VEC == 1 && q.upNx) {
@@ -371,7 +371,7 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
                     }
         }
         __syncthreads();
-        if (ks > 0 || !inside) return;
+        if (ks > 0 || (!inside && !MSE)) return;
 #pragma unroll
         for (int s2 = 0; s2 < KS - 1; ++s2)
 #pragma unroll
@@ -384,6 +384,66 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
                         acc[v][i][j].x += red[(s2 * NV + e) * 64 + threadIdx.x];
                         acc[v][i][j].y += red[(s2 * NV + e + 1) * 64 + threadIdx.x];
                     }
+    }
+    if (MSE) {
+        // tile = pair-local reconstruction O_b[d'] (rows d' = r, cols b = c); compare with X_b[d'] = B[k = r][c]
+        float part = 0.f;
+        if (inside) {
+            float2 beta[TR];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) beta[i] = make_float2(0.f, 0.f);
+            if (bx == 0) {                                    // this wave holds the DC bin (lane 0): wave-parallel bias term
+#pragma unroll
+                for (int i = 0; i < TR; ++i) {
+                    const int rr = (r0 + i < q.R) ? r0 + i : q.R - 1;
+                    float sx = 0.f, sy = 0.f;
+                    for (int m = threadIdx.x; m < q.mse.dM; m += 64) {
+                        const float2 f = q.mse.F[((long)rr * q.mse.dM + m) * q.P];
+                        const float bb = q.mse.b[m];
+                        sx = fmaf(f.x, bb, sx); sy = fmaf(f.y, bb, sy);
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); }
+                    beta[i] = make_float2((sx / (float)q.R + q.mse.p[rr]) * q.mse.norm, sy / (float)q.R * q.mse.norm);
+                }
+            }
+            float w[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const unsigned j = (unsigned)((grp * VEC + v) % q.mse.Nyr);
+                w[v] = (j > 0 && j < (unsigned)q.mse.Nyr - 1) ? 2.f : 1.f;        // Hermitian half-plane: interior columns count twice
+            }
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j) {
+                    if (r0 + i >= q.R || c0 + j >= q.C) continue;
+                    const V t = L::ld(rb, boff[j], (unsigned)(r0 + i) * b_ks);
+                    const float* tf = reinterpret_cast<const float*>(&t);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        float ox = acc[v][i][j].x, oy = acc[v][i][j].y;
+                        if (v == 0 && grp == 0) { ox += beta[i].x; oy += beta[i].y; }
+                        const float ex = tf[2 * v] - ox, ey = tf[2 * v + 1] - oy;
+                        part = fmaf(w[v], ex * ex + ey * ey, part);
+                    }
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        const float sc = q.mse.scale / q.mse.nfull;
+        // one atomic per workgroup, spread over MSE_SLOTS addresses (64 B apart): device-scope float atomics on ONE
+        // address retire at ~22 ns each on MI355X (measured), which made a 2112-workgroup launch take 35 us
+        float* slot = q.mse.acc + (blockIdx.x % MSE_SLOTS) * MSE_SLOT_STRIDE;
+        if (KS > 1) { if (threadIdx.x == 0 && part != 0.f) atomicAdd(slot, part * sc); return; }
+        if (threadIdx.x == 0) red[threadIdx.y] = part;
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            float s = 0.f;
+            for (int y = 0; y < (int)blockDim.y; ++y) s += red[y];
+            if (s != 0.f) atomicAdd(slot, s * sc);
+        }
+        return;
     }
     const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
     const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
@@ -418,14 +478,15 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
 }
 
 // FL: 0 = plain (conv_k), 1 = a*conj(b) with fused subtraction (the S contraction),
-//     2 = dual launch: problem 0 conj(a)*b (dc), problem 1 a*conj(b) (df)
+//     2 = dual launch: problem 0 conj(a)*b (dc), problem 1 a*conj(b) (df), 3 = plain with the MSE epilogue (no store)
 template <int VEC, int TR, int TC, int FL, int KS>
 __global__ __launch_bounds__(256) void contract_fast_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
 {
-    __shared__ float red[KS > 1 ? (KS - 1) * VEC * TR * TC * 2 * 64 : 1];
+    __shared__ float red[KS > 1 ? (KS - 1) * VEC * TR * TC * 2 * 64 : 4];
     const BlockId b = xcd_decode(gx, gy, gz);
     if (!b.ok) return;                                   // uniform per workgroup
-    if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false, KS>(qq.q[0], b.bx, b.by, b.bz, red);
+    if (FL == 3) contract_fast_body<VEC, TR, TC, false, false, false, KS, true>(qq.q[0], b.bx, b.by, b.bz, red);
+    else if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false, KS>(qq.q[0], b.bx, b.by, b.bz, red);
     else if (FL == 1) contract_fast_body<VEC, TR, TC, false, true, true, KS>(qq.q[0], b.bx, b.by, b.bz, red);
     else {
         if (b.bz < z0) contract_fast_body<VEC, TR, TC, true, false, false, KS>(qq.q[0], b.bx, b.by, b.bz, red);
@@ -451,6 +512,89 @@ template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_fa
     return hipGetLastError();
 }
 
+static bool contract_even(const Contract& q);
+// ---- grouped launch: several problems, one grid.  Each problem owns a contiguous, 8-aligned range of linear
+// workgroup ids (so the XCD-aware decode keeps working inside its range).
+__device__ __forceinline__ BlockId xcd_decode_lin(int lin, int gx, int gy, int gz)
+{
+    BlockId b;
+    if (gx < 64) {
+        b.bx = lin % gx;
+        const int rest = lin / gx;
+        b.by = rest % gy; b.bz = rest / gy;
+        b.ok = b.bz < gz;
+        return b;
+    }
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int per = gy * gz;
+    b.bx = (slot / per) * 8 + xcd;
+    const int rest = slot - (slot / per) * per;
+    b.by = rest % gy; b.bz = rest / gy;
+    b.ok = b.bx < gx && b.bz < gz;
+    return b;
+}
+
+template <int VEC, int TR, int TC, int FL, int KS>
+__global__ __launch_bounds__(256) void contract_group_kernel(const ContractN g)
+{
+    __shared__ float red[KS > 1 ? (KS - 1) * VEC * TR * TC * 2 * 64 : 1];
+    const int lin = blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && lin >= g.start[i]) p = i;
+    const BlockId b = xcd_decode_lin(lin - g.start[p], g.gx[p], g.gy[p], g.gz[p]);
+    if (!b.ok) return;                                   // uniform per workgroup
+    if (FL == 0) contract_fast_body<VEC, TR, TC, false, false, false, KS>(g.q[p], b.bx, b.by, b.bz, red);
+    else if (FL == 1) contract_fast_body<VEC, TR, TC, false, true, true, KS>(g.q[p], b.bx, b.by, b.bz, red);
+    else {
+        if (p < g.nA) contract_fast_body<VEC, TR, TC, true, false, false, KS>(g.q[p], b.bx, b.by, b.bz, red);
+        else contract_fast_body<VEC, TR, TC, false, true, false, KS>(g.q[p], b.bx, b.by, b.bz, red);
+    }
+}
+
+template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_group_tile(ContractN& g, hipStream_t st)
+{
+    const int by = 4;
+    int total = 0;
+    for (int p = 0; p < g.n; ++p) {
+        const Contract& q = g.q[p];
+        const long groups = (q.P + VEC - 1) / VEC;
+        const int rtiles = (q.R + TR - 1) / TR;
+        g.gx[p] = (int)((groups + 63) / 64);
+        g.gy[p] = KS > 1 ? rtiles : (rtiles + by - 1) / by;
+        g.gz[p] = (q.C + TC - 1) / TC;
+        g.start[p] = total;
+        total += (int)((xcd_grid(g.gx[p], g.gy[p], g.gz[p]) + 7) / 8 * 8);
+    }
+    g.start[g.n] = total;
+    contract_group_kernel<VEC, TR, TC, FL, KS><<<dim3(total), dim3(64, by), 0, st>>>(g);
+    return hipGetLastError();
+}
+
+hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8 || cls < 0 || cls > 2) return hipErrorInvalidValue;
+    bool even = true;
+    int Cmin = 1 << 30, Rmin = 1 << 30, Kmax = 0;
+    for (int p = 0; p < g.n; ++p) {
+        const Contract& q = g.q[p];
+        if (q.R <= 0 || q.C <= 0 || q.K <= 0 || q.P <= 0) return hipErrorInvalidValue;
+        const double a = ((double)(q.R - 1) * q.a_r + (double)(q.K - 1) * q.a_k + q.P) * 8.0;
+        const double b = ((double)(q.C - 1) * q.b_c + (double)(q.K - 1) * q.b_k + q.P) * 8.0;
+        if (a >= 4.0e9 || b >= 4.0e9 || q.upNx || q.Out2) return hipErrorInvalidValue;     // callers fall back to per-problem launches
+        even = even && contract_even(q);
+        Cmin = std::min(Cmin, q.C); Rmin = std::min(Rmin, q.R); Kmax = std::max(Kmax, q.K);
+    }
+    if (Rmin < 2 || Cmin < 2) return hipErrorInvalidValue;
+    const int vec = even ? 2 : 1, tc = Cmin >= 4 ? 4 : 2;
+    const bool ks = Kmax >= 16;
+#define AEFFT_CG(V, C_, F) if (vec == V && tc == C_ && cls == F) return ks ? contract_group_tile<V, 2, C_, F, 4>(g, st) : contract_group_tile<V, 2, C_, F, 1>(g, st);
+    AEFFT_CG(2, 4, 0) AEFFT_CG(2, 4, 1) AEFFT_CG(2, 4, 2) AEFFT_CG(2, 2, 0) AEFFT_CG(2, 2, 1) AEFFT_CG(2, 2, 2)
+    AEFFT_CG(1, 4, 0) AEFFT_CG(1, 4, 1) AEFFT_CG(1, 4, 2) AEFFT_CG(1, 2, 0) AEFFT_CG(1, 2, 1) AEFFT_CG(1, 2, 2)
+#undef AEFFT_CG
+    return hipErrorInvalidValue;
+}
+
 // which lean instantiation (if any) serves this launch: -1 = none (generic kernel)
 static int contract_fast_class(const Contract2& qq)
 {
@@ -462,6 +606,7 @@ static int contract_fast_class(const Contract2& qq)
     for (int p = 0; p < qq.n; ++p) if (!fits32(qq.q[p]) || (!qq.q[p].biasAfterFirst && qq.q[p].bias)) return -1;
     if (qq.q[0].Out2 && (qq.n != 1 || qq.q[0].conjA || qq.q[0].conjB || qq.q[0].A2)) return -1;
     const Contract& a = qq.q[0];
+    if (a.mse.acc) return (qq.n == 1 && !a.conjA && !a.conjB && !a.A2 && !a.upNx && !a.Out2 && a.R == a.K) ? 3 : -1;
     if (qq.n == 1) {
         if (!a.conjA && !a.conjB && !a.A2) return 0;
         if (!a.conjA && a.conjB && a.A2 && !a.upNx) return 1;
@@ -677,14 +822,17 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         if (V * R_ * C_ <= 16 && splitk) { \
             if (fc == 0) return contract_fast_tile<V, R_, C_, 0, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); \
             if (fc == 1) return contract_fast_tile<V, R_, C_, 1, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); \
+            if (fc == 3) return contract_fast_tile<V, R_, C_, 3, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); \
             return contract_fast_tile<V, R_, C_, 2, (V * R_ * C_ <= 16 ? 4 : 1)>(qq, st); } \
         if (fc == 0) return contract_fast_tile<V, R_, C_, 0, 1>(qq, st); \
         if (fc == 1) return contract_fast_tile<V, R_, C_, 1, 1>(qq, st); \
+        if (fc == 3) return contract_fast_tile<V, R_, C_, 3, 1>(qq, st); \
         return contract_fast_tile<V, R_, C_, 2, 1>(qq, st); }
         AEFFT_CF(2, 4, 4) AEFFT_CF(2, 4, 2) AEFFT_CF(2, 2, 4) AEFFT_CF(2, 2, 2)
         AEFFT_CF(1, 4, 4) AEFFT_CF(1, 4, 2) AEFFT_CF(1, 2, 4) AEFFT_CF(1, 2, 2)
 #undef AEFFT_CF
     }
+    if (qq.q[0].mse.acc) return hipErrorInvalidValue;        // the MSE epilogue exists only in the lean kernel: callers use conv, conv, diff_mse instead
 #define AEFFT_CT(V, R_, C_) if (vec == V && tr == R_ && tc == C_) return contract_tile<V, R_, C_>(qq, st);
     AEFFT_CT(2, 4, 4) AEFFT_CT(2, 4, 2) AEFFT_CT(2, 2, 4) AEFFT_CT(2, 2, 2) AEFFT_CT(2, 4, 1) AEFFT_CT(2, 1, 4) AEFFT_CT(2, 2, 1) AEFFT_CT(2, 1, 2) AEFFT_CT(2, 1, 1)
     AEFFT_CT(1, 4, 4) AEFFT_CT(1, 4, 2) AEFFT_CT(1, 2, 4) AEFFT_CT(1, 2, 2) AEFFT_CT(1, 4, 1) AEFFT_CT(1, 1, 4) AEFFT_CT(1, 2, 1) AEFFT_CT(1, 1, 2) AEFFT_CT(1, 1, 1)
@@ -866,6 +1014,34 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) db[m] = s * norm / den;
+}
+
+// sums (and clears) the slot accumulators of the MSE epilogue: out[l] += sum, copy[l] = out[l]
+__global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, int L)
+{
+    __shared__ float ws[MSE_SLOTS / 64];
+    for (int l = 0; l < L; ++l) {
+        float* s = slots + ((long)l * MSE_SLOTS + threadIdx.x) * MSE_SLOT_STRIDE;
+        float v = *s;
+        *s = 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = out[l];
+            for (int w = 0; w < MSE_SLOTS / 64; ++w) t += ws[w];
+            out[l] = t;
+            if (copy) copy[l] = t;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st)
+{
+    mse_finish_kernel<<<1, MSE_SLOTS, 0, st>>>(slots, out, copy, L);
+    return hipGetLastError();
 }
 
 hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
