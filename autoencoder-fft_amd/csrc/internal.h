@@ -60,7 +60,9 @@ struct Contract2 { Contract q[2]; int n; };   // up to two independent contracti
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 // Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):
 // cls 0 = plain conv_k, 1 = S (a*conj(b), fused subtraction), 2 = first nA problems conj(a)*b (dc), the rest a*conj(b) (df).
-struct ContractN { Contract q[8]; int n, nA; int gx[8], gy[8], gz[8], start[9]; };
+struct ContractN { Contract q[8]; int n, nA; int gx[8], gy[8], gz[8], start[9], ks[8], xmin; };
+// matrix-core (MFMA 4x4x1, block = bin) kernel for any mix of classes; hipErrorInvalidValue = not served, use the scalar kernels
+hipError_t launch_contract_mfma(ContractN& g, hipStream_t st);
 hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st);
 hipError_t launch_contract(const Contract& q, hipStream_t st);
 

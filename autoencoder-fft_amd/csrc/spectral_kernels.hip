@@ -21,26 +21,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "device_util.h"
+
 namespace aefft {
 
 __device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b)
 {
     acc.x += a.x * b.x - a.y * b.y;
     acc.y += a.x * b.y + a.y * b.x;
-}
-
-// destination bin of source bin (i, j) under the spectral crop [Nx][Ny/2+1] -> [Nxs][Nys/2+1] (inverse of fft.cu:102-111), or -1
-__device__ __forceinline__ long crop_dest(long bin, int Nx, int Ny, int Nxs, int Nys)
-{
-    const int Nyr = Ny / 2 + 1, Nyrs = Nys / 2 + 1;
-    const int i = (int)(bin / Nyr), j = (int)(bin - (long)i * Nyr);
-    int di = -1, dj = -1;
-    if (i < Nxs / 2) di = i;
-    else if (i == Nx / 2) di = Nxs / 2;
-    else if (i > Nx - Nxs / 2) di = i - Nx + Nxs;
-    if (j < Nyrs - 1) dj = j;
-    else if (j == Nyr - 1) dj = Nyrs - 1;
-    return (di >= 0 && dj >= 0) ? (long)di * Nyrs + dj : -1;
 }
 
 // Thread layout: threadIdx.x = 64 consecutive bin groups (VEC bins each: one float2 or float4 per
@@ -176,31 +164,6 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
 // XCD has its own 4 MiB L2.  Bins are independent, so the launch is 1-D and decoded such that all
 // workgroups whose bin tile is congruent to x mod 8 land on XCD x: each L2 then caches 1/8 of every
 // operand instead of all of it (8x less fabric traffic; speed only -- any placement is correct).
-struct BlockId { int bx, by, bz; bool ok; };
-__device__ __forceinline__ BlockId xcd_decode(int gx, int gy, int gz)
-{
-    const int lin = blockIdx.x;
-    BlockId b;
-    if (gx < 64) {
-        // too few bin tiles to give every XCD an equal share: plain order (bin tile fastest), all XCDs busy
-        b.bx = lin % gx;
-        const int rest = lin / gx;
-        b.by = rest % gy; b.bz = rest / gy;
-        b.ok = b.bz < gz;
-        return b;
-    }
-    // bin tile slowest: the gy*gz workgroups that re-read the same A / B bins run back to back on ONE XCD, so the
-    // re-reads hit that XCD's L2 instead of going back to HBM (decisive when the tensors exceed the caches)
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int per = gy * gz;
-    b.bx = (slot / per) * 8 + xcd;
-    const int rest = slot - (slot / per) * per;
-    b.by = rest % gy; b.bz = rest / gy;
-    b.ok = b.bx < gx && b.bz < gz;
-    return b;
-}
-static unsigned xcd_grid(long gx, int gy, int gz) { return gx < 64 ? (unsigned)(gx * gy * gz) : (unsigned)(((gx + 7) / 8) * 8 * gy * gz); }
-
 template <int VEC, int TR, int TC>
 __global__ __launch_bounds__(256) void contract_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
 {
@@ -238,21 +201,6 @@ template <int VEC, int TR, int TC> static hipError_t contract_tile(const Contrac
 //   * the operand scaling x/dM is applied once to the sum (sum_d (x/dM) c == (sum_d x c)/dM up to
 //     float32 rounding; power-of-two dM: bit-identical unless an intermediate is subnormal).
 // ------------------------------------------------------------------------------------------
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-
-template <int VEC> struct BufLoad;
-template <> struct BufLoad<1> {
-    typedef float2 T;
-    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-    { v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); return make_float2(__int_as_float(v.x), __int_as_float(v.y)); }
-};
-template <> struct BufLoad<2> {
-    typedef float4 T;
-    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-    { v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)); }
-};
-
 // four scalar FMAs per complex MAC (conjugation folded into the signs); the file is built with
 // -fno-slp-vectorize because hipcc otherwise packs these into v_pk_mul/v_pk_add/v_pk_fma triples
 // (5 packed instructions per complex MAC instead of 4 plain FMAs)
@@ -515,25 +463,6 @@ template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_fa
 static bool contract_even(const Contract& q);
 // ---- grouped launch: several problems, one grid.  Each problem owns a contiguous, 8-aligned range of linear
 // workgroup ids (so the XCD-aware decode keeps working inside its range).
-__device__ __forceinline__ BlockId xcd_decode_lin(int lin, int gx, int gy, int gz)
-{
-    BlockId b;
-    if (gx < 64) {
-        b.bx = lin % gx;
-        const int rest = lin / gx;
-        b.by = rest % gy; b.bz = rest / gy;
-        b.ok = b.bz < gz;
-        return b;
-    }
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int per = gy * gz;
-    b.bx = (slot / per) * 8 + xcd;
-    const int rest = slot - (slot / per) * per;
-    b.by = rest % gy; b.bz = rest / gy;
-    b.ok = b.bx < gx && b.bz < gz;
-    return b;
-}
-
 template <int VEC, int TR, int TC, int FL, int KS>
 __global__ __launch_bounds__(256) void contract_group_kernel(const ContractN g)
 {
@@ -571,9 +500,12 @@ template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_gr
     return hipGetLastError();
 }
 
+static bool use_mfma() { static const char* off = getenv("AEFFT_NOMFMA"); return !off; }
+
 hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st)
 {
     if (g.n < 1 || g.n > 8 || cls < 0 || cls > 2) return hipErrorInvalidValue;
+    if (use_mfma()) { const hipError_t e = launch_contract_mfma(g, st); if (e != hipErrorInvalidValue) return e; }
     bool even = true;
     int Cmin = 1 << 30, Rmin = 1 << 30, Kmax = 0;
     for (int p = 0; p < g.n; ++p) {
@@ -789,6 +721,13 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         if (q.R <= 0 || q.C <= 0 || q.K <= 0 || q.P <= 0) return hipErrorInvalidValue;
         even = even && contract_even(q);          // the float4 path needs 16-byte aligned plane offsets and no remap
         Rmin = std::min(Rmin, q.R); Cmin = std::min(Cmin, q.C);
+    }
+    if (use_mfma()) {                                          // matrix-core kernel first; it declines (InvalidValue) what it does not serve
+        ContractN g{};
+        for (int p = 0; p < qq.n; ++p) g.q[p] = qq.q[p];
+        g.n = qq.n;
+        const hipError_t e = launch_contract_mfma(g, st);
+        if (e != hipErrorInvalidValue) return e;
     }
     static const char* force = getenv("AEFFT_CONTRACT");     // dev switch: reg | lds
     bool lds = true;
