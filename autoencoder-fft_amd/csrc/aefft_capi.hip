@@ -1134,11 +1134,16 @@ static int grads_grouped(aefft_net* n)
         for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_S(q.X, q.X, q.O, q.S, n->B, q.dD, q.P); }
         RET_IF(do_contract_group(ctx, qs, m, m, 1));
     }
-    // dc | df: one dual launch per pair (the shapes differ too much across pairs for one tile configuration)
-    for (int l = n->L - 1; l >= 0; --l) {
-        Pair& q = n->pr[l];
-        const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
-        RET_IF(do_contract2(ctx, mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm), mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm)));
+    // dc | df of every pair in one launch (8 problems)
+    for (int l0 = 0; l0 < n->L; l0 += 4) {
+        const int m = std::min(4, n->L - l0);
+        for (int i = 0; i < m; ++i) {
+            Pair& q = n->pr[l0 + i];
+            const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+            qs[i] = mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm);
+            qs[m + i] = mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm);
+        }
+        RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
     }
     for (int l = 0; l < n->L; ++l) RET_IF(bias_and_kgrad(n, n->pr[l]));
     return AEFFT_OK;
@@ -1180,7 +1185,43 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
                          q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->mse_post + l));
         RET_IF(pair_spectra(n, q));
     }
-    for (int l = 0; l < n->L; ++l) RET_IF(reforward_mse(n, n->pr[l], n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE));
+    // post-update MSE (fft_backproplib.cu:1460-1463): G = F.C of every eligible pair in one launch, then every pair's pass
+    // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
+    {
+        static const char* nofuse = getenv("AEFFT_NOFUSEMSE");
+        static const char* nogroup = getenv("AEFFT_NOGROUP");
+        Contract gq[8], mq[8];
+        int m = 0;
+        std::vector<int> rest;
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            if (!nofuse && !nogroup && q.dD >= 2 && n->B >= 2 && m < 8) {
+                gq[m] = mk_G(q.F, q.C, q.S, q.dM, q.dD, q.P);
+                mq[m] = mk_gmse(q.S, q.X, q.F, q.b, q.p, n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, n->B, q.dM, q.dD, q.Nx, q.Ny);
+                ++m;
+            } else rest.push_back(l);
+        }
+        bool grouped = false;
+        if (m > 1) {
+            RET_IF(do_contract_group(ctx, gq, m, m, 0));
+            ContractN g{};
+            double bytes = 0;
+            for (int i = 0; i < m; ++i) { g.q[i] = mq[i]; bytes += ((double)mq[i].R * mq[i].K + 2.0 * mq[i].K * mq[i].C) * mq[i].P * 8.0; }
+            g.n = m;
+            hipError_t e;
+            {
+                Bracket br(ctx, KID_CONTRACT, bytes);
+                e = launch_contract_mfma(g, ctx->cur);
+            }
+            if (e == hipSuccess) grouped = true;
+            else if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(mse group)", e);
+            else (void)hipGetLastError();
+        }
+        for (int l = 0; l < n->L; ++l) {
+            const bool in_group = grouped && std::find(rest.begin(), rest.end(), l) == rest.end();
+            if (!in_group) RET_IF(reforward_mse(n, n->pr[l], n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE));
+        }
+    }
     {
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
         hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur);     // also the copy-out to mse_d

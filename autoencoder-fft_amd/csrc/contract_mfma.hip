@@ -375,11 +375,15 @@ hipError_t launch_contract_mfma(ContractN& g, hipStream_t st)
     long w2 = 0;
     for (int p = 0; p < g.n; ++p) { const Contract& q = g.q[p]; w2 += ((q.P + 31) / 32) * ((q.R + 3) / 4) * ((q.C + 3) / 4); }
     int vec = (even && w2 >= 2048) ? 2 : 1;
-    int ksplit = (Kmin >= 32 && (long)Rmax * Cmax <= 1024 && Pmin <= 4096) ? 4 : 1;
-    int trb = 1, tcb = (Cmax >= 8 && ksplit == 1 && !diff) ? 2 : 1;
+    bool anysplit = false;
+    for (int p = 0; p < g.n; ++p) {
+        const Contract& q = g.q[p];
+        g.ks[p] = (q.K >= 32 && (long)q.R * q.C <= 1024 && q.P <= 4096) ? 4 : 1;
+        anysplit = anysplit || g.ks[p] > 1;
+    }
+    int trb = 1, tcb = (Cmax >= 8 && !anysplit && !diff) ? 2 : 1;
     const char* tile = getenv("AEFFT_MTILE");              // dev switch: "v,r,c,ks" (read per launch so that a sweep can change it)
-    if (tile) { int v_, r_, c_, k_; if (sscanf(tile, "%d,%d,%d,%d", &v_, &r_, &c_, &k_) == 4) { if (even || v_ == 1) vec = v_; trb = r_; tcb = c_; ksplit = (k_ > 1 && Kmin >= 4) ? 4 : 1; } }
-    for (int p = 0; p < g.n; ++p) g.ks[p] = ksplit;
+    if (tile) { int v_, r_, c_, k_; if (sscanf(tile, "%d,%d,%d,%d", &v_, &r_, &c_, &k_) == 4) { if (even || v_ == 1) vec = v_; trb = r_; tcb = c_; for (int p = 0; p < g.n; ++p) g.ks[p] = (k_ > 1 && Kmin >= 4) ? 4 : 1; } }
     const char* xm = getenv("AEFFT_XCDMIN");
     g.xmin = xm ? atoi(xm) : 64;
 #define AEFFT_MT(V, R_, C_) if (vec == V && trb == R_ && tcb == C_) return diff ? contract_mfma_tile<V, R_, C_, true>(g, st) : contract_mfma_tile<V, R_, C_, false>(g, st);
