@@ -516,6 +516,20 @@ static int do_update(aefft_ctx* ctx, float* c, float* f, float* b, float* p, con
     return AEFFT_OK;
 }
 
+static UpdateArgs mk_update(float* c, float* f, float* b, float* p, const float* dck, const float* dfk, const float* db, const float* dp,
+                            Momentum mo, int dM, int dD, int Nk, int Nl, float del, int sym, float gscale, float* zero)
+{
+    UpdateArgs a{};
+    a.zero = zero;
+    a.c = c; a.f = f; a.b = b; a.p = p;
+    a.dck = dck; a.dfk = dfk; a.db = db; a.dp = dp;
+    a.Dc = mo.Dc; a.Df = mo.Df; a.Db = mo.Db; a.Dp = mo.Dp;
+    a.dM = dM; a.dD = dD; a.Nk = Nk; a.Nl = Nl;
+    a.del = del; a.alpha = 0.9f; a.w0 = 1.f; a.w1 = 10.f;      // fft_backproplib.cu:608,1252
+    a.gscale = sym ? 0.5f * gscale : gscale; a.sym = sym;
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------
 // op-level C entry points
 // ------------------------------------------------------------------------------------------
@@ -1145,6 +1159,53 @@ static int grads_grouped(aefft_net* n)
         }
         RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
     }
+    // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
+    static const char* nogroup = getenv("AEFFT_NOGROUP");
+    bool same = n->L > 1 && n->L <= 8 && !nogroup;
+    for (int l = 0; l < n->L && same; ++l) {
+        const Pair& q = n->pr[l];
+        same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
+        same = same && q.Ny / 2 + 1 <= 256;
+    }
+    if (same) {
+        BiasGradGroup bg{};
+        PrunedGroup pg{};
+        double bbytes = 0, kbytes = 0;
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            float* g = n->grad + q.goff;
+            const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+            bg.a[l] = BiasGradArgs{q.O, q.X, q.F, q.b, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
+                                   (float)q.Nx * (float)q.Ny, grad_norm(q.dM, q.dD, q.Nx, q.Ny)};
+            pg.q[l] = PrunedProb{q.dc, g, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
+            bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
+            kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
+        }
+        bg.n = pg.n = n->L;
+        {
+            Bracket br(ctx, KID_BIASGRAD, bbytes);
+            hipError_t e = launch_bias_grad_group(bg, ctx->cur);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "bias_grad(group)", e);
+        }
+        hipError_t e;
+        {
+            Bracket br(ctx, KID_KGRAD, kbytes);
+            e = launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+        }
+        if (e == hipSuccess) return AEFFT_OK;
+        if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kgrad(group)", e);
+        (void)hipGetLastError();
+        for (int l = 0; l < n->L; ++l) {          // bias terms are done; only the transforms pair by pair
+            Pair& q = n->pr[l];
+            float* g = n->grad + q.goff;
+            const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+            const long planes = (long)q.dM * q.dD;
+            if (q.part) { RET_IF(do_c2r_shrink(ctx, q.dc, g, nullptr, q.part, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl)); continue; }
+            RET_IF(do_c2r_shrink(ctx, q.dc, g, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+            RET_IF(do_c2r_shrink(ctx, q.df, g + nk, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
+        }
+        return AEFFT_OK;
+    }
     for (int l = 0; l < n->L; ++l) RET_IF(bias_and_kgrad(n, n->pr[l]));
     return AEFFT_OK;
 }
@@ -1177,7 +1238,43 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
 static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gscale, float* mse_d)
 {
     aefft_ctx* ctx = n->ctx;
-    for (int l = 0; l < n->L; ++l) {
+    static const char* nogroup1 = getenv("AEFFT_NOGROUP");
+    bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
+    for (int l = 0; l < n->L && grouped_w; ++l) {
+        const Pair& q = n->pr[l];
+        grouped_w = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny) && q.Ny / 2 + 1 <= 256;
+    }
+    if (grouped_w) {
+        UpdateGroup ug{};
+        PrunedGroup pg{};
+        double ubytes = 0, kbytes = 0;
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            float* g = n->grad + q.goff;
+            const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+            ug.a[l] = mk_update(q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
+                                q.dM, q.dD, q.Nk, q.Nl, del, sym, gscale, n->mse_post + l);
+            pg.q[l] = PrunedProb{q.c, q.C, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
+            ubytes += (double)nk * 4.0 * 8;
+            kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
+        }
+        ug.n = pg.n = n->L;
+        {
+            Bracket br(ctx, KID_UPDATE, ubytes);
+            hipError_t e = launch_update_group(ug, ctx->cur);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
+        }
+        hipError_t e;
+        {
+            Bracket br(ctx, KID_KSPEC, kbytes);
+            e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+        }
+        if (e != hipSuccess) {
+            if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kspec(group)", e);
+            (void)hipGetLastError();
+            for (int l = 0; l < n->L; ++l) RET_IF(pair_spectra(n, n->pr[l]));
+        }
+    } else for (int l = 0; l < n->L; ++l) {
         Pair& q = n->pr[l];
         float* g = n->grad + q.goff;
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;

@@ -74,6 +74,10 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullabl
 hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
                             int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st);
 
+struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; };
+struct BiasGradGroup { BiasGradArgs a[8]; int n; int start[9], fix[8]; };
+hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st);
+
 // ---- pruned_kernels.hip ----------------------------------------------------------------
 // Kernel-support-pruned transforms: only Nk x Nl taps are non-zero going forward / needed coming back,
 // so pad+R2C and C2R+shrink become direct DFT evaluations (fft.cu:1219-1226 and :1274-1282 fused).
@@ -81,6 +85,11 @@ bool pruned_supported(int Nk, int Nl, int Nx, int Ny);
 hipError_t launch_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);
 hipError_t launch_kgrad(const float2* D, float* g, float* part /*workspace: kgrad_partial_floats()*/, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, float scale, hipStream_t st);
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
+// The same transforms for up to 8 problems with equal (Nk, Nl) in ONE launch (kgrad: no row chunks, so no ksum pass).
+struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale; };
+struct PrunedGroup { PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8]; };
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
+hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()
 
 // ---- update_kernels.hip ----------------------------------------------------------------
@@ -98,7 +107,9 @@ struct UpdateArgs {
     float *ddc, *ddf, *ddb, *ddp;         // optional: record the gradients used (adapt_rate, backproplib.cu:33); may be null
     float* zero;                          // optional: one float set to 0 (the pair's MSE accumulator, saves a memset launch)
 };
-hipError_t launch_update(const UpdateArgs& a, hipStream_t st);                                      // fft.cu:605 / 657
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
+struct UpdateGroup { UpdateArgs a[8]; int n; int start[9]; };
+hipError_t launch_update_group(UpdateGroup& g, hipStream_t st);                                       // up to 8 pairs, one launch                                      // fft.cu:605 / 657
 hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
                                 float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st);   // fft.cu:709
 

@@ -34,19 +34,18 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
 // it is formed once per thread (25 real x complex FMAs) and every output row then costs 5 complex multiplies with
 // the row phases (LDS broadcast reads).  Consecutive threads own consecutive columns: coalesced stores.
 template <int NK, int NL>
-__global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ kern, float2* __restrict__ K,
+__device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float2* __restrict__ K,
                                                     const float2* __restrict__ tw, long planes, int Nx, int Ny,
-                                                    int rows_per_chunk, int ppb)
+                                                    int rows_per_chunk, int ppb, int bx, int by, float2* lds)
 {
-    extern __shared__ float2 lds[];
     const int Nyr = Ny / 2 + 1;
     float2* rowph = lds;                                 // [rows_per_chunk][NK]
-    const int i0 = blockIdx.y * rows_per_chunk;
+    const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
     for (int t = threadIdx.x; t < nrows * NK; t += blockDim.x) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, 1.f);
     __syncthreads();
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
-    const long plane = (long)blockIdx.x * ppb + pl;
+    const long plane = (long)bx * ppb + pl;
     if (pl >= ppb || plane >= planes) return;
     float2 v[NK];
     {
@@ -74,25 +73,47 @@ __global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ ke
     }
 }
 
+template <int NK, int NL>
+__global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ kern, float2* __restrict__ K,
+                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny,
+                                                    int rows_per_chunk, int ppb)
+{
+    extern __shared__ float2 lds[];
+    kspec_body<NK, NL>(kern, K, tw, planes, Nx, Ny, rows_per_chunk, ppb, blockIdx.x, blockIdx.y, lds);
+}
+
+// all pairs' kernel spectra in one launch: problem p owns workgroups [start[p], start[p+1]), plane groups fastest
+template <int NK, int NL>
+__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw)
+{
+    extern __shared__ float2 lds[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const int lin = blockIdx.x - g.start[p];
+    const PrunedProb& q = g.q[p];
+    kspec_body<NK, NL>(static_cast<const float*>(q.src), static_cast<float2*>(q.dst), tw, q.planes, q.Nx, q.Ny, g.rows[p], g.ppb[p],
+                       lin % g.pblocks[p], lin / g.pblocks[p], lds);
+}
+
 // Thread <-> (plane, column j) over a chunk of RB rows:
 //   t_k[j]   = sum_i D[i][j] * e^{+2 pi i i*kap_k/Nx}                  (row phases: LDS broadcast reads; D read once, coalesced)
 //   g[k][l] += w_j * Re( t_k[j] * e^{+2 pi i j*lam_l/Ny} )              (summed over the plane's columns through LDS, fixed order)
 // Output: part[plane][chunk][NK*NL] (summed over chunks by ksum_kernel when chunks > 1).  Deterministic.
 template <int NK, int NL>
-__global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D, float* __restrict__ part,
-                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny, int RB, int ppb, float scale)
+__device__ __forceinline__ void kgrad_body(const float2* __restrict__ D, float* __restrict__ part,
+                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny, int RB, int ppb, float scale,
+                                                    int bx, int chunk, int nchunks, float2* lds)
 {
-    extern __shared__ float2 lds[];
     const int Nyr = Ny / 2 + 1;
     const int nthr = blockDim.x;
     float2* rowph = lds;                                            // [RB][NK]
     float* contrib = reinterpret_cast<float*>(rowph + RB * NK);     // [NK*NL][nthr]
-    const int chunk = blockIdx.y, nchunks = gridDim.y;
     const int i0 = chunk * RB;
     for (int t = threadIdx.x; t < RB * NK; t += nthr) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, -1.f);
     __syncthreads();
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
-    const long plane = (long)blockIdx.x * ppb + pl;
+    const long plane = (long)bx * ppb + pl;
     const bool active = pl < ppb && plane < planes;
     float2 t[NK];
 #pragma unroll
@@ -102,6 +123,19 @@ __global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D
         // batches of 8 rows: all 8 loads are issued before the first use (hipcc does not pipeline loads across
         // loop iterations by itself, and this loop is otherwise one memory round trip per row)
         int i = 0;
+        for (; i + 16 <= RB; i += 16) {
+            float2 d[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) d[u] = src[(long)(i + u) * Nyr];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const float2 rp = rowph[(i + u) * NK + k];
+                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
+                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
+                }
+        }
         for (; i + 8 <= RB; i += 8) {
             float2 d[8];
 #pragma unroll
@@ -135,12 +169,121 @@ __global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D
     __syncthreads();
     for (int it = threadIdx.x; it < ppb * NK * NL; it += nthr) {
         const int p2 = it / (NK * NL), kl = it - p2 * (NK * NL);
-        const long pln = (long)blockIdx.x * ppb + p2;
+        const long pln = (long)bx * ppb + p2;
         if (pln >= planes) continue;
         float g = 0.f;
         for (int jj = 0; jj < Nyr; ++jj) g += contrib[kl * nthr + p2 * Nyr + jj];
         part[(pln * nchunks + chunk) * (NK * NL) + kl] = g * scale;
     }
+}
+
+template <int NK, int NL>
+__global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D, float* __restrict__ part,
+                                                    const float2* __restrict__ tw, long planes, int Nx, int Ny, int RB, int ppb, float scale)
+{
+    extern __shared__ float2 lds[];
+    kgrad_body<NK, NL>(D, part, tw, planes, Nx, Ny, RB, ppb, scale, blockIdx.x, blockIdx.y, gridDim.y, lds);
+}
+
+// Grouped form: all pairs' pruned inverse transforms in ONE launch and without partial sums in HBM.  A workgroup of NT
+// threads owns ppb planes; thread <-> (row slice s, plane, column j), so a 256-row plane is walked by S slices in
+// parallel (3 load round trips instead of 16) and the slices are combined in LDS in a fixed order (deterministic).
+template <int NK, int NL, int NT>
+__device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, float* __restrict__ g, const float2* __restrict__ tw,
+                                                  long planes, int Nx, int Ny, int ppb, int S, float scale, int bx, float2* lds)
+{
+    constexpr int TS = NT + 1;                                      // row stride of the t arrays (+1: the NK rows land in different banks)
+    const int Nyr = Ny / 2 + 1;
+    float2* rowph = lds;                                            // [Nx][NK]   e^{+2 pi i i kap_k / Nx}
+    float2* colph = rowph + Nx * NK;                                // [Nyr][NL]  e^{+2 pi i j lam_l / Ny}
+    float* tre = reinterpret_cast<float*>(colph + Nyr * NL);        // [NK][TS]   per-thread row sums t_k (real part)
+    float* tim = tre + NK * TS;                                     // [NK][TS]
+    for (int t = threadIdx.x; t < Nx * NK; t += NT) rowph[t] = phase(tw, t / NK, t % NK - NK / 2, Nx, -1.f);
+    for (int t = threadIdx.x; t < Nyr * NL; t += NT) colph[t] = phase(tw, t / NL, t % NL - NL / 2, Ny, -1.f);
+    __syncthreads();
+    const int per = ppb * Nyr;
+    const int s = threadIdx.x / per, rem = threadIdx.x - s * per;
+    const int pl = rem / Nyr, j = rem - pl * Nyr;
+    const long plane = (long)bx * ppb + pl;
+    const bool active = s < S && plane < planes;
+    const int RB = (Nx + S - 1) / S;
+    const int i0 = s * RB, nrows = active ? min(RB, Nx - i0) : 0;
+    float2 t[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) t[k] = make_float2(0.f, 0.f);
+    if (nrows > 0) {
+        const float2* src = D + (plane * Nx + i0) * (long)Nyr + j;
+        const float2* rp0 = rowph + i0 * NK;
+        int i = 0;
+        for (; i + 16 <= nrows; i += 16) {
+            float2 d[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) d[u] = src[(long)(i + u) * Nyr];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const float2 rp = rp0[(i + u) * NK + k];
+                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
+                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
+                }
+        }
+        if (i < nrows) {                                  // tail: clamped loads, masked accumulation (one more round trip, not nrows-i)
+            float2 d[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) d[u] = src[(long)min(i + u, nrows - 1) * Nyr];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (i + u >= nrows) break;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const float2 rp = rp0[(i + u) * NK + k];
+                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
+                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { tre[k * TS + threadIdx.x] = t[k].x; tim[k * TS + threadIdx.x] = t[k].y; }
+    }
+    __syncthreads();
+    if (active && s == 0) {                               // row slices -> slice 0, in slice order
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float a = tre[k * TS + rem], b = tim[k * TS + rem];
+            for (int s2 = 1; s2 < S; ++s2) { a += tre[k * TS + s2 * per + rem]; b += tim[k * TS + s2 * per + rem]; }
+            tre[k * TS + rem] = a; tim[k * TS + rem] = b;
+        }
+    }
+    __syncthreads();
+    // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ), columns in order
+    for (int it = threadIdx.x; it < ppb * NK * NL; it += NT) {
+        const int p2 = it / (NK * NL), kl = it - p2 * (NK * NL);
+        const int k = kl / NL, l = kl - k * NL;
+        const long pln = (long)bx * ppb + p2;
+        if (pln >= planes) continue;
+        float a = 0.f;
+        for (int jj = 0; jj < Nyr; ++jj) {
+            const float2 cp = colph[jj * NL + l];
+            const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
+            a += wj * (tre[k * TS + p2 * Nyr + jj] * cp.x - tim[k * TS + p2 * Nyr + jj] * cp.y);
+        }
+        g[pln * (NK * NL) + kl] = a * scale;
+    }
+}
+
+template <int NK, int NL, int NT>
+__global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, const float2* __restrict__ tw)
+{
+    extern __shared__ float2 lds[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const PrunedProb& q = g.q[p];
+    kgrad_sliced_body<NK, NL, NT>(static_cast<const float2*>(q.src), static_cast<float*>(q.dst), tw, q.planes, q.Nx, q.Ny, g.ppb[p], g.rows[p],
+                                  q.scale, blockIdx.x - g.start[p], lds);
 }
 
 // g[e] = sum_chunk part[plane][chunk][tap]
@@ -220,6 +363,78 @@ static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2
     const long n = planes * NK * NL;
     ksum_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(part, g, n, NK * NL, chunks);
     return hipGetLastError();
+}
+
+template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st)
+{
+    int total = 0; size_t lds = 0;
+    long pb_all = 0;
+    for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); pb_all += (g.q[p].planes + g.ppb[p] - 1) / g.ppb[p]; }
+    for (int p = 0; p < g.n; ++p) {
+        const PrunedProb& q = g.q[p];
+        g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
+        int chunks = 1;                                   // rows split until the LAUNCH has ~2048 workgroups (>= 8 rows each)
+        while (pb_all * chunks < 2048 && q.Nx / (chunks * 2) >= 8) chunks *= 2;
+        g.rows[p] = (q.Nx + chunks - 1) / chunks;
+        g.start[p] = total; total += g.pblocks[p] * chunks;
+        lds = std::max(lds, kspec_lds(g.rows[p], NK));
+    }
+    g.start[g.n] = total;
+    kspec_group_kernel<NK, NL><<<dim3(total), 256, lds, st>>>(g, tw);
+    return hipGetLastError();
+}
+
+template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st)
+{
+    constexpr int NT = 1024;
+    int total = 0; size_t lds = 0;
+    for (int p = 0; p < g.n; ++p) {
+        const PrunedProb& q = g.q[p];
+        const int Nyr = q.Ny / 2 + 1;
+        if (Nyr > NT) return hipErrorInvalidValue;
+        // planes per workgroup as in the single-problem kernel (~256 columns), the remaining threads become row slices (>= 8 rows each)
+        g.ppb[p] = std::max(1, std::min(256, NT) / Nyr);
+        int S = std::max(1, NT / (g.ppb[p] * Nyr));
+        while (S > 1 && q.Nx / S < 8) --S;
+        g.rows[p] = S;
+        g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
+        g.start[p] = total; total += g.pblocks[p];
+        lds = std::max(lds, sizeof(float2) * ((size_t)q.Nx * NK + (size_t)Nyr * NL) + sizeof(float) * 2 * NK * (NT + 1));
+    }
+    g.start[g.n] = total;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kgrad_group_kernel<NK, NL, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    kgrad_group_kernel<NK, NL, NT><<<dim3(total), NT, lds, st>>>(g, tw);
+    return hipGetLastError();
+}
+
+static bool pruned_group_ok(const PrunedGroup& g, const float2* tw, int Nk, int Nl)
+{
+    if (g.n < 1 || g.n > 8 || !tw) return false;
+    for (int p = 0; p < g.n; ++p) {
+        const PrunedProb& q = g.q[p];
+        if (q.planes <= 0 || !pruned_supported(Nk, Nl, q.Nx, q.Ny) || q.Ny / 2 + 1 > 256) return false;   // 256-thread workgroups: one thread per column
+    }
+    return true;
+}
+
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)
+{
+    if (!pruned_group_ok(g, tw, Nk, Nl)) return hipErrorInvalidValue;
+    if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st);
+    if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st);
+    return run_kspec_group<7, 7>(g, tw, st);
+}
+
+hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)
+{
+    if (!pruned_group_ok(g, tw, Nk, Nl)) return hipErrorInvalidValue;
+    if (Nk == 3) return run_kgrad_group<3, 3>(g, tw, st);
+    if (Nk == 5) return run_kgrad_group<5, 5>(g, tw, st);
+    return run_kgrad_group<7, 7>(g, tw, st);
 }
 
 hipError_t launch_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st)

@@ -909,12 +909,11 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 //   db[m]       = Re( sum_d1 es[d1] * conj(F[d1][m](0,0)) ) * norm / (Norm*B)      (fft_backproplib.cu:432,465)
 //   dp[d]       = Re es[d] * norm / (Norm*B)                                       (:471)
 //   df[d][m](0,0) += es[d] * b[m]*norm / (Norm*B)    -- the b0 term of :448-455 (H' bias at DC)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict__ O, const float2* __restrict__ T,
+__device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
                                                         const float2* __restrict__ F, const float* __restrict__ b,
                                                         float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
-                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es)
 {
-    extern __shared__ float2 es[];
     float* esf = reinterpret_cast<float*>(es);
     for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
     __syncthreads();
@@ -928,8 +927,8 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
     }
     __syncthreads();
     const float den = Norm * (float)B;
-    if ((int)blockIdx.x < fix_blocks) {
-        const int t = blockIdx.x * 256 + threadIdx.x;
+    if (blk < fix_blocks) {
+        const int t = blk * 256 + threadIdx.x;
         if (t < dD * dM) {
             const int d = t / dM, m = t - d * dM;
             const float2 e = es[d];
@@ -943,7 +942,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
         return;
     }
     // db: one wave per output map m, lanes over d1
-    const int m = ((int)blockIdx.x - fix_blocks) * 4 + (threadIdx.x >> 6);
+    const int m = (blk - fix_blocks) * 4 + (threadIdx.x >> 6);
     if (m >= dM) return;
     float s = 0.f;
     for (int d1 = threadIdx.x & 63; d1 < dD; d1 += 64) {
@@ -980,6 +979,40 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
 hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st)
 {
     mse_finish_kernel<<<1, MSE_SLOTS, 0, st>>>(slots, out, copy, L);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict__ O, const float2* __restrict__ T,
+                                                        const float2* __restrict__ F, const float* __restrict__ b,
+                                                        float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
+{
+    extern __shared__ float2 es[];
+    bias_grad_body(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks, blockIdx.x, es);
+}
+
+__global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGroup g)
+{
+    extern __shared__ float2 es[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const BiasGradArgs& a = g.a[p];
+    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es);
+}
+
+hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
+    int total = 0, dDmax = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const BiasGradArgs& a = g.a[i];
+        g.fix[i] = (a.dM * a.dD + 255) / 256;
+        g.start[i] = total; total += g.fix[i] + (a.dM + 3) / 4;
+        dDmax = std::max(dDmax, a.dD);
+    }
+    g.start[g.n] = total;
+    bias_grad_group_kernel<<<dim3(total), 256, sizeof(float2) * dDmax, st>>>(g);
     return hipGetLastError();
 }
 

@@ -70,10 +70,10 @@ __device__ __forceinline__ float clip_step(float g, float D, float del, float al
     return (1 - alpha) * del * g / ((10 < ag) ? ag : 10) + alpha * D;
 }
 
-__global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a)
+__device__ __forceinline__ void update_body(const UpdateArgs& a, int blk)
 {
     const int n = a.dM * a.dD * a.Nk * a.Nl;
-    const int idk = blockIdx.x * 256 + threadIdx.x;
+    const int idk = blk * 256 + threadIdx.x;
     if (idk == 0 && a.zero) *a.zero = 0.f;
     if (idk >= n) return;
     const bool multi = a.cd != nullptr;
@@ -114,6 +114,32 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a)
         const float Dp = clip_step(g, a.Dp[idk], a.del, a.alpha);
         a.p[idk] += -Dp; a.Dp[idk] = Dp;
     }
+}
+
+__global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) { update_body(a, blockIdx.x); }
+
+// every pair's update in one launch (the pairs are independent; each launch otherwise costs ~4.7 us for ~1 us of work)
+__global__ __launch_bounds__(256) void update_group_kernel(const UpdateGroup g)
+{
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    update_body(g.a[p], blockIdx.x - g.start[p]);
+}
+
+hipError_t launch_update_group(UpdateGroup& g, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
+    int total = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const UpdateArgs& a = g.a[i];
+        const int n = a.dM * a.dD * a.Nk * a.Nl;
+        if (n < a.dM || n < a.dD) return hipErrorInvalidValue;
+        g.start[i] = total; total += (n + 255) / 256;
+    }
+    g.start[g.n] = total;
+    update_group_kernel<<<dim3(total), 256, 0, st>>>(g);
+    return hipGetLastError();
 }
 
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
