@@ -365,6 +365,32 @@ static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, 
     return AEFFT_OK;
 }
 
+// pool_fft(conv_k(X)) without the full-resolution conv output (fft_backproplib.cu:1346-1348 when only the pooled
+// layer is consumed): Xs[b][r] on the [Nxs][Nys/2+1] grid.  Returns AEFFT_EUNSUPPORTED-like -1 when the kernel declines.
+static int do_conv_pooled(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* Xs, int B, int R, int K,
+                          int Nx, int Ny, int Nxs, int Nys, bool* done)
+{
+    *done = false;
+    const long P = bins(Nx, Ny), Ps = bins(Nxs, Nys);
+    Contract q{};
+    q.A = W; q.a_r = (long)K * P; q.a_k = P;
+    q.B = X; q.b_k = P; q.b_c = (long)K * P;
+    q.Out = Xs; q.o_r = Ps; q.o_c = (long)R * Ps;
+    q.R = R; q.C = B; q.K = K; q.P = Ps;
+    q.preDivB = (float)R;
+    q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
+    q.gdNx = Nx; q.gdNy = Ny; q.gdNxs = Nxs; q.gdNys = Nys;
+    hipError_t e;
+    {
+        Bracket br(ctx, KID_CONTRACT, ((double)R * K + (double)K * B + (double)R * B) * Ps * 8.0);
+        e = launch_contract(q, ctx->cur);
+    }
+    if (e == hipSuccess) { *done = true; return AEFFT_OK; }
+    if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(pooled)", e);
+    (void)hipGetLastError();
+    return AEFFT_OK;
+}
+
 // conv_k over a batch: O[b][r] = sum_k (X[b][k]/R) * W[r][k] (+ bias[r]*Nx*Ny at DC)
 static int do_conv(aefft_ctx* ctx, const float2* X, const float2* W, const float* bias, float2* O, int B, int R, int K, int Nx, int Ny,
                    float2* Ocrop = nullptr, int Nxs = 0, int Nys = 0)
@@ -735,6 +761,7 @@ struct Pair {
     float *Dc, *Df, *Db, *Dp;
     float2 *C, *F;
     bool spectra_valid;
+    bool H_stale = false;    // the last (lazy) forward produced only the pooled part of H: recompute before reading H
     float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
     size_t goff;             // offset (floats) of this pair's segment in the packed gradient buffer
     float* es;               // [2*dD] DC bins of the error summed over the batch (inside the net scratch)
@@ -970,7 +997,9 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     return AEFFT_OK;
 }
 
-extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* recon_d)
+// lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
+// discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
+static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool lazy)
 {
     if (!n || !frames_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_forward: bad argument");
     aefft_ctx* ctx = n->ctx;
@@ -983,6 +1012,14 @@ extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* rec
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
         static const char* nofuse = getenv("AEFFT_NOFUSECROP");
         const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !nofuse;
+        q.H_stale = false;
+        if (fuse && lazy) {
+            static const char* nolazy = getenv("AEFFT_NOLAZY");
+            const Pair& nx = n->pr[l + 1];
+            bool done = false;
+            if (!nolazy) RET_IF(do_conv_pooled(ctx, q.X, q.C, q.b, nx.X, B, q.dM, q.dD, q.Nx, q.Ny, nx.Nx, nx.Ny, &done));
+            if (done) { q.H_stale = true; continue; }
+        }
         if (fuse) { const Pair& nx = n->pr[l + 1]; RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny, nx.X, nx.Nx, nx.Ny)); }
         else RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, B, q.dM, q.dD, q.Nx, q.Ny));
         if (!fuse && l + 1 < L && n->pr[l + 1].s != 1) {
@@ -1006,6 +1043,8 @@ extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* rec
     return AEFFT_OK;
 }
 
+extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* recon_d) { return net_forward(n, frames_d, recon_d, false); }
+
 extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* ch, int* nx, int* ny)
 {
     if (!n || layer < 0 || layer > 4 * n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_layer: bad layer index");
@@ -1017,7 +1056,15 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     else if (layer <= 2 * L) {
         const Pair& q = n->pr[(layer - 1) / 2];
         x = xi = q.Nx; y = yi = q.Ny;
-        if (layer & 1) { c = q.dD; S = q.X; } else { c = q.dM; S = q.H; }
+        if (layer & 1) { c = q.dD; S = q.X; }
+        else {
+            c = q.dM; S = q.H;
+            if (out_d && q.H_stale) {          // hidden layer skipped by the training step's forward: form it now (fft_backproplib.cu:1347)
+                Pair& qm = n->pr[(layer - 1) / 2];
+                RET_IF(do_conv(n->ctx, qm.X, qm.C, qm.b, qm.H, n->B, qm.dM, qm.dD, qm.Nx, qm.Ny));
+                qm.H_stale = false;
+            }
+        }
     } else {
         const int nn = (layer - 1) / 2;           // decoder conv index L..2L-1
         const Pair& q = n->pr[2 * L - 1 - nn];
@@ -1331,7 +1378,7 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
 {
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
-    RET_IF(aefft_net_forward(n, frames_d, recon_d));
+    RET_IF(net_forward(n, frames_d, recon_d, true));
     const bool side = use_side_streams(n);
     if (!side) { RET_IF(grads_grouped(n)); n->have_grad = true; return AEFFT_OK; }
     RET_IF(fork_streams(ctx));

@@ -42,8 +42,15 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
     const bool tile_ok = r0 < q.R && c0 < q.C;                  // uniform per wave
     const bool binok = grp * VEC < q.P;
     const long gcl = binok ? grp : (q.P - 1) / VEC;             // loads of out-of-range lanes are clamped, never stored
-    long bgrp = gcl;
+    long bgrp = gcl, agrp = gcl;
     bool live = true;
+    if (VEC == 1 && q.gdNx) {                                   // both operands read at the source bin of this (small-grid) output bin: inverse of fft.cu:102-111
+        const int Nyr = q.gdNy / 2 + 1, Nyrs = q.gdNys / 2 + 1;
+        const int di = (int)(gcl / Nyrs), dj = (int)(gcl - (long)di * Nyrs);
+        const int si = di < q.gdNxs / 2 ? di : (di == q.gdNxs / 2 ? q.gdNx / 2 : di - q.gdNxs + q.gdNx);
+        const int sj = dj < Nyrs - 1 ? dj : Nyr - 1;
+        agrp = bgrp = (long)si * Nyr + sj;
+    }
     if (VEC == 1 && q.upNx) {                                   // B operand read through the zero-pad index map (fft.cu:117-152)
         const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
         const int i = (int)(gcl / Nyr), j = (int)(gcl - (long)i * Nyr);
@@ -61,7 +68,7 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, 0xFFFFFFFFu, 0x00020000);
     unsigned aoff[TRB], boff[TCB];
 #pragma unroll
-    for (int t = 0; t < TRB; ++t) { const int rr = (r0 + 4 * t + sub < q.R) ? r0 + 4 * t + sub : q.R - 1; aoff[t] = (unsigned)((rr * q.a_r + gcl * VEC) * 8); }
+    for (int t = 0; t < TRB; ++t) { const int rr = (r0 + 4 * t + sub < q.R) ? r0 + 4 * t + sub : q.R - 1; aoff[t] = (unsigned)((rr * q.a_r + agrp * VEC) * 8); }
 #pragma unroll
     for (int u = 0; u < TCB; ++u) { const int cc = (c0 + 4 * u + sub < q.C) ? c0 + 4 * u + sub : q.C - 1; boff[u] = (unsigned)((cc * q.b_c + bgrp * VEC) * 8); }
     const unsigned a_ks = (unsigned)(q.a_k * 8), b_ks = (unsigned)(q.b_k * 8);
@@ -348,12 +355,14 @@ template <int VEC, int TRB, int TCB, bool DIFF> static hipError_t contract_mfma_
 static bool mfma_eligible(const Contract& q)
 {
     if (q.R <= 0 || q.C <= 0 || q.K <= 0 || q.P <= 0) return false;
-    const double a = ((double)(q.R - 1) * q.a_r + (double)(q.K - 1) * q.a_k + q.P) * 8.0;
-    const double b = ((double)(q.C - 1) * q.b_c + (double)(q.K - 1) * q.b_k + q.P) * 8.0;
+    const double Pbig = q.gdNx ? (double)q.gdNx * (q.gdNy / 2 + 1) : (double)q.P;
+    const double a = ((double)(q.R - 1) * q.a_r + (double)(q.K - 1) * q.a_k + Pbig) * 8.0;
+    const double b = ((double)(q.C - 1) * q.b_c + (double)(q.K - 1) * q.b_k + Pbig) * 8.0;
     if (a >= 4.0e9 || b >= 4.0e9) return false;                     // 32-bit buffer offsets
     if (q.bias && !q.biasAfterFirst) return false;
     if (q.mse.acc && (q.R != q.K || q.conjA || q.conjB || q.A2 || q.upNx || q.Out2)) return false;
     if (q.Out2 && (q.o_r % q.P || q.o_c % q.P)) return false;
+    if (q.gdNx && (q.upNx || q.Out2 || q.mse.acc || q.P != (long)q.gdNxs * (q.gdNys / 2 + 1))) return false;
     return true;
 }
 
@@ -366,7 +375,7 @@ hipError_t launch_contract_mfma(ContractN& g, hipStream_t st)
     for (int p = 0; p < g.n; ++p) {
         const Contract& q = g.q[p];
         if (!mfma_eligible(q) || (q.A2 != nullptr) != diff) return hipErrorInvalidValue;
-        even = even && !((q.P & 1) || (q.a_r & 1) || (q.a_k & 1) || (q.b_k & 1) || (q.b_c & 1) || (q.o_r & 1) || (q.o_c & 1)) && !q.upNx;
+        even = even && !((q.P & 1) || (q.a_r & 1) || (q.a_k & 1) || (q.b_k & 1) || (q.b_c & 1) || (q.o_r & 1) || (q.o_c & 1)) && !q.upNx && !q.gdNx;
         Rmax = std::max(Rmax, q.R); Cmax = std::max(Cmax, q.C); Kmin = std::min(Kmin, q.K); Pmin = std::min(Pmin, q.P);
     }
     // Tile choice, from a sweep of every contraction of the cfg3 step on MI355X (tools_sweep.py): these launches are

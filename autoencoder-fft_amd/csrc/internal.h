@@ -47,6 +47,10 @@ struct Contract {
     // Fused spectral down-sampling of the OUTPUT (fft.cu:98-113): besides Out, every output bin that survives the
     // crop from [dnNx][dnNy/2+1] to [dnNxs][dnNys/2+1] is also written to Out2 (same [r][c] plane order, small planes).
     float2* Out2; int dnNx, dnNy, dnNxs, dnNys;   // Out2 == null: off
+    // Gather form of the same down-sampling (matrix-core kernel only): P counts the bins of the SMALL grid [gdNxs][gdNys/2+1];
+    // every output bin reads A and B at its source bin of the [gdNx][gdNy/2+1] grid (A/B strides are those of the big planes)
+    // and the bins the crop discards are never computed.  gdNx == 0: off.
+    int gdNx, gdNy, gdNxs, gdNys;
     // MSE epilogue instead of a store (mse.acc != null; needs R == K): with A = G[d'][d] = (F.C)/(dM*dD) of one pair and
     // B = X (the pair's input spectra) the tile holds the pair-local reconstruction O_b[d'] = sum_d G[d'][d] X_b[d] + beta[d']
     // at the DC bin (beta = Nx*Ny*(p[d'] + sum_m F[d'][m](0,0) b[m] / dD): the two bias terms of conv_k o conv_k,

@@ -729,6 +729,7 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         const hipError_t e = launch_contract_mfma(g, st);
         if (e != hipErrorInvalidValue) return e;
     }
+    for (int p = 0; p < qq.n; ++p) if (qq.q[p].gdNx) return hipErrorInvalidValue;     // gather form: matrix-core kernel only
     static const char* force = getenv("AEFFT_CONTRACT");     // dev switch: reg | lds
     bool lds = true;
     for (int p = 0; p < qq.n; ++p) lds = lds && contract_wants_lds(qq.q[p]);
