@@ -295,6 +295,29 @@ static Contract mk_S(const float2* Xin, const float2* T, const float2* O, float2
     q.R = dD; q.C = dD; q.K = B; q.P = P;
     return q;
 }
+// The same S when O is stored on the support of the up-sampled spectra only (Oc[b][d][s], s on the small grid):
+//   S = -sum_b X_b X_b^H  on every bin,   S[map(s)] += sum_b Oc_b[s] X_b[map(s)]^H  on the support.
+static Contract mk_XXneg(const float2* X, float2* S, int B, int dD, long P)
+{
+    Contract q{};
+    q.A = X; q.a_r = P; q.a_k = (long)dD * P;
+    q.B = X; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
+    q.Out = S; q.o_r = (long)dD * P; q.o_c = P;
+    q.R = dD; q.C = dD; q.K = B; q.P = P;
+    q.postDiv = -1.0f;
+    return q;
+}
+static Contract mk_OX(const float2* Oc, const float2* X, float2* S, int B, int dD, long P, long Pc, int Nx, int Ny, int NxC, int NyC)
+{
+    Contract q{};
+    q.A = Oc; q.a_r = Pc; q.a_k = (long)dD * Pc;
+    q.B = X; q.b_k = (long)dD * P; q.b_c = P; q.conjB = true;
+    q.Out = S; q.o_r = (long)dD * P; q.o_c = P;
+    q.R = dD; q.C = dD; q.K = B; q.P = Pc;
+    q.gdNx = Nx; q.gdNy = Ny; q.gdNxs = NxC; q.gdNys = NyC; q.gdMask = 2 | 4;
+    q.accumulate = true;
+    return q;
+}
 static Contract mk_dc(const float2* F, const float2* S, float2* dc, int B, int dM, int dD, long P, float Norm)
 {
     Contract q{};
@@ -379,7 +402,7 @@ static int do_conv_pooled(aefft_ctx* ctx, const float2* X, const float2* W, cons
     q.R = R; q.C = B; q.K = K; q.P = Ps;
     q.preDivB = (float)R;
     q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
-    q.gdNx = Nx; q.gdNy = Ny; q.gdNxs = Nxs; q.gdNys = Nys;
+    q.gdNx = Nx; q.gdNy = Ny; q.gdNxs = Nxs; q.gdNys = Nys; q.gdMask = 3;
     hipError_t e;
     {
         Bracket br(ctx, KID_CONTRACT, ((double)R * K + (double)K * B + (double)R * B) * Ps * 8.0);
@@ -762,6 +785,8 @@ struct Pair {
     float2 *C, *F;
     bool spectra_valid;
     bool H_stale = false;    // the last (lazy) forward produced only the pooled part of H: recompute before reading H
+    float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
+    bool O_stale = false;    // the last (lazy) forward produced Oc only: expand before reading O
     float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
     size_t goff;             // offset (floats) of this pair's segment in the packed gradient buffer
     float* es;               // [2*dD] DC bins of the error summed over the batch (inside the net scratch)
@@ -785,6 +810,9 @@ struct aefft_net {
     size_t mse_cap = 0;
     const float* last_frames = nullptr;
     bool have_forward = false, have_grad = false;
+    int NxC = 0, NyC = 0; long Pc = 0;   // grid of the coarsest pair = support of every decoder output
+    bool compact = true;                 // the training step may keep decoder outputs on that support only
+    bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
     bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
     // shared scratch sized for the largest pair
     bool fuse_crop = true;     // encoder convs also write the next pair's cropped input (no resize launches)
@@ -845,6 +873,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         if (q.s == 1 && l > 0) q.X = n->pr[l - 1].H;
         else if ((rc = net_alloc_t(n, &q.X, BDP))) break;
         if ((rc = net_alloc_t(n, &q.H, BMP)) || (rc = net_alloc_t(n, &q.O, BDP))) break;
+        q.Oc = nullptr;
         if ((rc = net_alloc_t(n, &q.S, (size_t)q.dD * q.dD * q.P)) || (rc = net_alloc_t(n, &q.dc, 2 * W))) break;
         q.df = q.dc + W;
         q.part = nullptr;
@@ -872,6 +901,14 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
             n->grad_n = goff;
             if (n->pr[0].s == 1) n->A0 = n->pr[0].X;
+            // compact decoder outputs (training step): the coarsest pair's grid
+            const Pair& qc = n->pr[n->L - 1];
+            n->NxC = qc.Nx; n->NyC = qc.Ny; n->Pc = qc.P;
+            for (int l = 0; l < n->L && rc == AEFFT_OK; ++l) {
+                Pair& q = n->pr[l];
+                if (l == n->L - 1) q.Oc = q.O;
+                else rc = net_alloc_t(n, &q.Oc, (size_t)n->B * q.dD * n->Pc);
+            }
         }
     }
     if (rc != AEFFT_OK) { aefft_net_destroy(n); return rc; }
@@ -1029,14 +1066,59 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     // decoder (:1356-1361): conv then zero-pad up-sampling.  The up-sampled tensor is never stored: the next
     // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
+    static const char* nocompact = getenv("AEFFT_NOCOMPACT");
+    bool compact = lazy && n->compact && !nocompact && L > 1;
     for (int l = L - 1; l >= 0; --l) {
         Pair& q = n->pr[l];
-        if (l == L - 1) RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
-        else { const Pair& in = n->pr[l + 1]; RET_IF(do_conv_up(ctx, in.O, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny, in.Nx, in.Ny)); }
+        q.O_stale = false;
+        if (l == L - 1) { RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny)); continue; }
+        const Pair& in = n->pr[l + 1];
+        if (compact) {
+            // Up-sampled spectra are zero outside the image of the coarsest grid, and conv_k maps zero to zero (the bias sits on
+            // the DC bin, inside it): every decoder output lives on those Pc bins.  The training step computes and stores only them:
+            //   Oc_l[b][d][s] = sum_m F_l[d][m][map_l(s)] * Oc_{l+1}[b][m][s] / dD + p[d] Nx Ny [s == 0]
+            Contract k{};
+            k.A = q.F; k.a_r = (long)q.dM * q.P; k.a_k = q.P;
+            k.B = in.Oc; k.b_k = n->Pc; k.b_c = (long)q.dM * n->Pc;
+            k.Out = q.Oc; k.o_r = n->Pc; k.o_c = (long)q.dD * n->Pc;
+            k.R = q.dD; k.C = B; k.K = q.dM; k.P = n->Pc;
+            k.preDivB = (float)q.dD;
+            k.bias = q.p; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
+            k.gdNx = q.Nx; k.gdNy = q.Ny; k.gdNxs = n->NxC; k.gdNys = n->NyC; k.gdMask = 1;
+            hipError_t e;
+            {
+                Bracket br(ctx, KID_CONTRACT, ((double)k.R * k.K + (double)k.K * k.C + (double)k.R * k.C) * k.P * 8.0);
+                e = launch_contract(k, ctx->cur);
+            }
+            if (e == hipSuccess) { q.O_stale = true; continue; }
+            if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(compact decoder)", e);
+            (void)hipGetLastError();
+            // declined: from here down the full-grid decoder; the levels already done are expanded first
+            n->compact = compact = false;
+            for (int l2 = L - 2; l2 > l; --l2) {
+                Pair& q2 = n->pr[l2];
+                RET_IF(do_resize(ctx, q2.Oc, q2.O, (long)B * q2.dD, n->NxC, n->NyC, q2.Nx, q2.Ny));
+                q2.O_stale = false;
+            }
+        }
+        RET_IF(do_conv_up(ctx, in.O, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny, in.Nx, in.Ny));
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
         Pair& q = n->pr[0];
-        RET_IF(do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny)));
+        static const char* nooverlap = getenv("AEFFT_NOOVERLAP");
+        const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
+        if (async) {
+            // training step: nothing downstream reads the reconstruction, so its (bandwidth-bound) inverse FFT runs on a side
+            // stream underneath the latency-bound gradient contractions; aefft_net_step_grad joins it before returning
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+            ctx->cur = ctx->aux[0];
+        }
+        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon_d, (long)B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny))
+                                 : do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny));
+        ctx->cur = ctx->stream;
+        RET_IF(rc);
+        n->recon_pending = async;
     }
     n->last_frames = frames_d;
     n->have_forward = true; n->have_grad = false;
@@ -1069,6 +1151,7 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
         const int nn = (layer - 1) / 2;           // decoder conv index L..2L-1
         const Pair& q = n->pr[2 * L - 1 - nn];
         c = q.dD; S = q.O; xi = q.Nx; yi = q.Ny;
+        if (q.O_stale) { S = q.Oc; xi = n->NxC; yi = n->NyC; }      // training-step forward: the layer is stored on its support only
         if (layer & 1) { x = q.Nx; y = q.Ny; } else { x = q.Nxin; y = q.Nyin; }   // odd: conv output; even: up-sampled
     }
     if (ch) *ch = c;
@@ -1083,12 +1166,22 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     return do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y));
 }
 
+// expand a decoder output that the training-step forward kept on its support only
+static int ensure_O(aefft_net* n, Pair& q)
+{
+    if (!q.O_stale) return AEFFT_OK;
+    RET_IF(do_resize(n->ctx, q.Oc, q.O, (long)n->B * q.dD, n->NxC, n->NyC, q.Nx, q.Ny));
+    q.O_stale = false;
+    return AEFFT_OK;
+}
+
 // gradient half of one loop-body iteration on pair q: needs X (= T, autoencoder.cpp:194) and the current O.
 static int pair_grad(aefft_net* n, Pair& q)
 {
     aefft_ctx* ctx = n->ctx;
     float* g = n->grad + q.goff;
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+    RET_IF(ensure_O(n, q));
     RET_IF(do_gradient(ctx, q.X, q.X, q.O, q.C, q.F, q.b, q.S, q.dc, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.Nx, q.Ny));
     const long planes = (long)q.dM * q.dD;
     if (q.part) return do_c2r_shrink(ctx, q.dc, g, nullptr, q.part, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl);   // dc|df -> dck|dfk, one launch
@@ -1118,6 +1211,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     aefft_ctx* ctx = n->ctx;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
     Pair& q = n->pr[l];
+    RET_IF(ensure_O(n, q));
     if ((size_t)(n_iter + 1) > n->mse_cap) {
         float* nm;
         RET_IF(net_alloc_t(n, &nm, (size_t)n_iter + 1));
@@ -1171,6 +1265,7 @@ static bool use_side_streams(const aefft_net* n) { return n->ctx->concurrency &&
 // the independent contractions of a phase (4 x S, 4 x dc + 4 x df, 4 + 4 re-forward convs) go out as one launch each.
 static int bias_and_kgrad(aefft_net* n, Pair& q)
 {
+    RET_IF(ensure_O(n, q));
     aefft_ctx* ctx = n->ctx;
     float* g = n->grad + q.goff;
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
@@ -1190,9 +1285,22 @@ static int grads_grouped(aefft_net* n)
 {
     aefft_ctx* ctx = n->ctx;
     Contract qs[8];
+    bool comp = false;
+    for (int l = 0; l < n->L; ++l) comp = comp || n->pr[l].O_stale;
     for (int l0 = 0; l0 < n->L; l0 += 4) {
         const int m = std::min(4, n->L - l0);
-        for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_S(q.X, q.X, q.O, q.S, n->B, q.dD, q.P); }
+        if (!comp) {
+            for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_S(q.X, q.X, q.O, q.S, n->B, q.dD, q.P); }
+            RET_IF(do_contract_group(ctx, qs, m, m, 1));
+            continue;
+        }
+        for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_XXneg(q.X, q.S, n->B, q.dD, q.P); }
+        RET_IF(do_contract_group(ctx, qs, m, m, 1));
+        for (int i = 0; i < m; ++i) {
+            Pair& q = n->pr[l0 + i];
+            qs[i] = q.O_stale ? mk_OX(q.Oc, q.X, q.S, n->B, q.dD, q.P, n->Pc, q.Nx, q.Ny, n->NxC, n->NyC)
+                              : mk_OX(q.O, q.X, q.S, n->B, q.dD, q.P, q.P, q.Nx, q.Ny, q.Nx, q.Ny);
+        }
         RET_IF(do_contract_group(ctx, qs, m, m, 1));
     }
     // dc | df of every pair in one launch (8 problems)
@@ -1222,8 +1330,8 @@ static int grads_grouped(aefft_net* n)
             Pair& q = n->pr[l];
             float* g = n->grad + q.goff;
             const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
-            bg.a[l] = BiasGradArgs{q.O, q.X, q.F, q.b, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
-                                   (float)q.Nx * (float)q.Ny, grad_norm(q.dM, q.dD, q.Nx, q.Ny)};
+            bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
+                                   (float)q.Nx * (float)q.Ny, grad_norm(q.dM, q.dD, q.Nx, q.Ny), q.O_stale ? n->Pc : q.P};
             pg.q[l] = PrunedProb{q.dc, g, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
             bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
             kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
@@ -1380,14 +1488,23 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     aefft_ctx* ctx = n->ctx;
     RET_IF(net_forward(n, frames_d, recon_d, true));
     const bool side = use_side_streams(n);
-    if (!side) { RET_IF(grads_grouped(n)); n->have_grad = true; return AEFFT_OK; }
+    if (!side) {
+        RET_IF(grads_grouped(n));
+        if (n->recon_pending) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+            n->recon_pending = false;
+        }
+        n->have_grad = true;
+        return AEFFT_OK;
+    }
     RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;
     for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {     // small (launch-bound) pairs first, the big ones fill in
         if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
         rc = pair_grad(n, n->pr[l]);
     }
-    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; }
+    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; n->recon_pending = false; }
     RET_IF(rc);
     n->have_grad = true;
     return AEFFT_OK;

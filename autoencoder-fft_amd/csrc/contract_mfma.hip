@@ -42,14 +42,17 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
     const bool tile_ok = r0 < q.R && c0 < q.C;                  // uniform per wave
     const bool binok = grp * VEC < q.P;
     const long gcl = binok ? grp : (q.P - 1) / VEC;             // loads of out-of-range lanes are clamped, never stored
-    long bgrp = gcl, agrp = gcl;
+    long bgrp = gcl, agrp = gcl, ogrp = grp;
     bool live = true;
-    if (VEC == 1 && q.gdNx) {                                   // both operands read at the source bin of this (small-grid) output bin: inverse of fft.cu:102-111
+    if (VEC == 1 && q.gdNx) {                                   // small-grid bin -> its bin on the big grid (inverse of fft.cu:102-111)
         const int Nyr = q.gdNy / 2 + 1, Nyrs = q.gdNys / 2 + 1;
         const int di = (int)(gcl / Nyrs), dj = (int)(gcl - (long)di * Nyrs);
         const int si = di < q.gdNxs / 2 ? di : (di == q.gdNxs / 2 ? q.gdNx / 2 : di - q.gdNxs + q.gdNx);
         const int sj = dj < Nyrs - 1 ? dj : Nyr - 1;
-        agrp = bgrp = (long)si * Nyr + sj;
+        const long big = (long)si * Nyr + sj;
+        if (q.gdMask & 1) agrp = big;
+        if (q.gdMask & 2) bgrp = big;
+        if (q.gdMask & 4) ogrp = big;
     }
     if (VEC == 1 && q.upNx) {                                   // B operand read through the zero-pad index map (fft.cu:117-152)
         const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
@@ -283,7 +286,14 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
                     if (v == 0 && q.bias && grp == 0) x += q.bias[row] * q.biasScale;
                     of[2 * v] = x * omul; of[2 * v + 1] = y * omul;
                 }
-                Op[(row * q.o_r + col * q.o_c) / VEC + grp] = o;
+                V* dst = Op + (row * q.o_r + col * q.o_c) / VEC + ogrp;
+                if (q.accumulate) {
+                    const V prev = *dst;
+                    const float* pf = reinterpret_cast<const float*>(&prev);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2 * VEC; ++e2) of[e2] += pf[e2];
+                }
+                *dst = o;
                 if (q.Out2) {
                     const long plane = (long)row * orp + (long)col * ocp;
 #pragma unroll
@@ -356,6 +366,7 @@ static bool mfma_eligible(const Contract& q)
 {
     if (q.R <= 0 || q.C <= 0 || q.K <= 0 || q.P <= 0) return false;
     const double Pbig = q.gdNx ? (double)q.gdNx * (q.gdNy / 2 + 1) : (double)q.P;
+    if (q.gdNx && (q.gdNxs > q.gdNx || q.gdNys > q.gdNy || !q.gdMask)) return false;
     const double a = ((double)(q.R - 1) * q.a_r + (double)(q.K - 1) * q.a_k + Pbig) * 8.0;
     const double b = ((double)(q.C - 1) * q.b_c + (double)(q.K - 1) * q.b_k + Pbig) * 8.0;
     if (a >= 4.0e9 || b >= 4.0e9) return false;                     // 32-bit buffer offsets

@@ -47,10 +47,13 @@ struct Contract {
     // Fused spectral down-sampling of the OUTPUT (fft.cu:98-113): besides Out, every output bin that survives the
     // crop from [dnNx][dnNy/2+1] to [dnNxs][dnNys/2+1] is also written to Out2 (same [r][c] plane order, small planes).
     float2* Out2; int dnNx, dnNy, dnNxs, dnNys;   // Out2 == null: off
-    // Gather form of the same down-sampling (matrix-core kernel only): P counts the bins of the SMALL grid [gdNxs][gdNys/2+1];
-    // every output bin reads A and B at its source bin of the [gdNx][gdNy/2+1] grid (A/B strides are those of the big planes)
-    // and the bins the crop discards are never computed.  gdNx == 0: off.
-    int gdNx, gdNy, gdNxs, gdNys;
+    // Small-grid iteration (matrix-core kernel only): P counts the bins of the SMALL grid [gdNxs][gdNys/2+1]; bin s of it
+    // corresponds to bin map(s) of the [gdNx][gdNy/2+1] grid (the index map of pool_fft, fft.cu:102-111 / 117-152).
+    // gdMask selects which tensors live on the BIG grid and are addressed at map(s): 1 = A (and A2), 2 = B, 4 = Out.
+    // Uses: conv_k + down-sampling without the discarded bins (A|B big, Out small); the decoder on the support of the
+    // up-sampled spectra (A big); gradient terms of an up-sampled operand (B, Out big).  gdNx == 0: off.
+    int gdNx, gdNy, gdNxs, gdNys, gdMask;
+    bool accumulate;                    // Out += result (the element is owned by one lane: no race)
     // MSE epilogue instead of a store (mse.acc != null; needs R == K): with A = G[d'][d] = (F.C)/(dM*dD) of one pair and
     // B = X (the pair's input spectra) the tile holds the pair-local reconstruction O_b[d'] = sum_d G[d'][d] X_b[d] + beta[d']
     // at the DC bin (beta = Nx*Ny*(p[d'] + sum_m F[d'][m](0,0) b[m] / dD): the two bias terms of conv_k o conv_k,
@@ -78,7 +81,7 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullabl
 hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
                             int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st);
 
-struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; };
+struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; long PO; /* plane stride of O (== P unless O is stored on its support only) */ };
 struct BiasGradGroup { BiasGradArgs a[8]; int n; int start[9], fix[8]; };
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st);
 

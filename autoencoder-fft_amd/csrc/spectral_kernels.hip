@@ -913,7 +913,7 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
                                                         const float2* __restrict__ F, const float* __restrict__ b,
                                                         float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
-                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es)
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO)
 {
     float* esf = reinterpret_cast<float*>(es);
     for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
@@ -921,8 +921,7 @@ __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, con
     // (frame, channel) pairs spread over the threads so the B*dD DC-bin loads are all in flight at once
     for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
         const int d = idx % dD;
-        const long q = (long)idx * P;
-        const float2 o = O[q], t = T[q];
+        const float2 o = O[(long)idx * PO], t = T[(long)idx * P];
         atomicAdd(&esf[2 * d], o.x - t.x);
         atomicAdd(&esf[2 * d + 1], o.y - t.y);
     }
@@ -989,7 +988,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
                                                         int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
 {
     extern __shared__ float2 es[];
-    bias_grad_body(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks, blockIdx.x, es);
+    bias_grad_body(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks, blockIdx.x, es, P);
 }
 
 __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGroup g)
@@ -999,7 +998,7 @@ __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGrou
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const BiasGradArgs& a = g.a[p];
-    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es);
+    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es, a.PO);
 }
 
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st)
