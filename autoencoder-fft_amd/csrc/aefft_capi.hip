@@ -20,7 +20,7 @@ enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
     KID_R2C_ROWS = 0, KID_R2C_COLS, KID_C2R_COLS, KID_C2R_ROWS, KID_CONTRACT, KID_RESIZE, KID_DIFFMSE, KID_BIASGRAD,
-    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_COUNT
+    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_WGRAD, KID_COUNT
 };
 
 struct ProfEvent { hipEvent_t a, b; int kid; double bytes; };
@@ -175,7 +175,7 @@ extern "C" int aefft_prof_reset(aefft_ctx* ctx)
 }
 
 static const char* kid_names[KID_COUNT] = {"r2c_rows", "r2c_cols", "c2r_cols", "c2r_rows", "contract", "resize", "diff_mse",
-                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad"};
+                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad", "weight_taps"};
 
 extern "C" int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes)
 {
@@ -785,6 +785,7 @@ struct Pair {
     float2 *C, *F;
     bool spectra_valid;
     bool H_stale = false;    // the last (lazy) forward produced only the pooled part of H: recompute before reading H
+    float* Q = nullptr;      // [dD][dD][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip)
     float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
     bool O_stale = false;    // the last (lazy) forward produced Oc only: expand before reading O
     float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
@@ -908,6 +909,10 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
                 Pair& q = n->pr[l];
                 if (l == n->L - 1) q.Oc = q.O;
                 else rc = net_alloc_t(n, &q.Oc, (size_t)n->B * q.dD * n->Pc);
+                if (rc == AEFFT_OK && q.Nk == q.Nl && (q.Nk == 3 || q.Nk == 5)) {
+                    const size_t tt = (size_t)(2 * q.Nk - 1) * (2 * q.Nk - 1);
+                    rc = net_alloc_t(n, &q.Q, (size_t)q.dD * q.dD * tt);
+                }
             }
         }
     }
@@ -1303,17 +1308,6 @@ static int grads_grouped(aefft_net* n)
         }
         RET_IF(do_contract_group(ctx, qs, m, m, 1));
     }
-    // dc | df of every pair in one launch (8 problems)
-    for (int l0 = 0; l0 < n->L; l0 += 4) {
-        const int m = std::min(4, n->L - l0);
-        for (int i = 0; i < m; ++i) {
-            Pair& q = n->pr[l0 + i];
-            const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
-            qs[i] = mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm);
-            qs[m + i] = mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm);
-        }
-        RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
-    }
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
     static const char* nogroup = getenv("AEFFT_NOGROUP");
     bool same = n->L > 1 && n->L <= 8 && !nogroup;
@@ -1322,21 +1316,48 @@ static int grads_grouped(aefft_net* n)
         same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
         same = same && q.Ny / 2 + 1 <= 256;
     }
+    static const char* noq = getenv("AEFFT_NOQPATH");
+    bool qpath = same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
+    for (int l = 0; l < n->L && qpath; ++l) qpath = n->pr[l].Q != nullptr;
     if (same) {
         BiasGradGroup bg{};
         PrunedGroup pg{};
-        double bbytes = 0, kbytes = 0;
+        WgradGroup wg{};
+        double bbytes = 0, kbytes = 0, wbytes = 0;
+        const int T = 2 * n->pr[0].Nk - 1;
         for (int l = 0; l < n->L; ++l) {
             Pair& q = n->pr[l];
             float* g = n->grad + q.goff;
             const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
-            bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
-                                   (float)q.Nx * (float)q.Ny, grad_norm(q.dM, q.dD, q.Nx, q.Ny), q.O_stale ? n->Pc : q.P};
-            pg.q[l] = PrunedProb{q.dc, g, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
+            const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+            bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, qpath ? nullptr : q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
+                                   (float)q.Nx * (float)q.Ny, Norm, q.O_stale ? n->Pc : q.P, qpath ? q.es : nullptr};
             bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
-            kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
+            if (qpath) {
+                // weight gradients through Q = pruned inverse transform of S on the (2Nk-1)^2 offsets (weight_kernels.hip): no dc|df spectra
+                pg.q[l] = PrunedProb{q.S, q.Q, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
+                wg.q[l] = WgradProb{q.c, q.f, q.Q, q.es, q.b, g, g + nk, q.dM, q.dD, 1.0f / (Norm * (float)n->B), (float)q.Nx * (float)q.Ny};
+                kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
+                wbytes += (2.0 * nk + (double)q.dD * q.dD * T * T) * 4.0 + 2.0 * nk * 4.0;
+            } else {
+                pg.q[l] = PrunedProb{q.dc, g, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
+                kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
+            }
         }
-        bg.n = pg.n = n->L;
+        bg.n = pg.n = wg.n = n->L;
+        if (!qpath) {
+            // dc | df of every pair in one launch (8 problems)
+            for (int l0 = 0; l0 < n->L; l0 += 4) {
+                const int m = std::min(4, n->L - l0);
+                for (int i = 0; i < m; ++i) {
+                    Pair& q = n->pr[l0 + i];
+                    const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+                    qs[i] = mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm);
+                    qs[m + i] = mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm);
+                }
+                RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
+            }
+        }
         {
             Bracket br(ctx, KID_BIASGRAD, bbytes);
             hipError_t e = launch_bias_grad_group(bg, ctx->cur);
@@ -1345,10 +1366,16 @@ static int grads_grouped(aefft_net* n)
         hipError_t e;
         {
             Bracket br(ctx, KID_KGRAD, kbytes);
-            e = launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+            e = qpath ? launch_kgrad_group_taps(pg, ctx->tw, T, ctx->cur) : launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+        }
+        if (e == hipSuccess && qpath) {
+            Bracket br(ctx, KID_WGRAD, wbytes);
+            e = launch_wgrad_taps_group(wg, n->pr[0].Nk, ctx->cur);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "wgrad(group)", e);
+            return AEFFT_OK;
         }
         if (e == hipSuccess) return AEFFT_OK;
-        if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kgrad(group)", e);
+        if (e != hipErrorInvalidValue || qpath) return fail(ctx, AEFFT_EHIP, "kgrad(group)", e);
         (void)hipGetLastError();
         for (int l = 0; l < n->L; ++l) {          // bias terms are done; only the transforms pair by pair
             Pair& q = n->pr[l];
@@ -1360,6 +1387,17 @@ static int grads_grouped(aefft_net* n)
             RET_IF(do_c2r_shrink(ctx, q.df, g + nk, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
         }
         return AEFFT_OK;
+    }
+    // pairs with different kernel supports: dc | df per group of pairs, then pair by pair
+    for (int l0 = 0; l0 < n->L; l0 += 4) {
+        const int m = std::min(4, n->L - l0);
+        for (int i = 0; i < m; ++i) {
+            Pair& q = n->pr[l0 + i];
+            const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
+            qs[i] = mk_dc(q.F, q.S, q.dc, n->B, q.dM, q.dD, q.P, Norm);
+            qs[m + i] = mk_df(q.C, q.S, q.df, n->B, q.dM, q.dD, q.P, Norm);
+        }
+        RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
     }
     for (int l = 0; l < n->L; ++l) RET_IF(bias_and_kgrad(n, n->pr[l]));
     return AEFFT_OK;

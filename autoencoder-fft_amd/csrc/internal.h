@@ -81,7 +81,8 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullabl
 hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, const float* b, float2* df, float* db, float* dp,
                             int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st);
 
-struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; long PO; /* plane stride of O (== P unless O is stored on its support only) */ };
+struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; long PO; /* plane stride of O (== P unless O is stored on its support only) */
+                      float* es_out; /* nullable: [2*dD] floats, es[d] = sum_b (O_b[d] - T_b[d])(0,0) */ };
 struct BiasGradGroup { BiasGradArgs a[8]; int n; int start[9], fix[8]; };
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st);
 
@@ -97,6 +98,14 @@ struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float s
 struct PrunedGroup { PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8]; };
 hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
+// the inverse transform on a T x T support with T = 5 or 9 (the offsets kl + k'l' of 3x3 / 5x5 kernels, weight_kernels.hip)
+hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);
+
+// ---- weight_kernels.hip ----------------------------------------------------------------
+struct WgradProb { const float *c, *f, *Q, *es, *b; float *gc, *gf; int dM, dD; float inv_den, norm; };   // Q [dD][dD][T*T], es [2*dD]
+struct WgradGroup { WgradProb q[8]; int n; int start[9]; };
+hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st);
+
 const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()
 
 // ---- update_kernels.hip ----------------------------------------------------------------

@@ -394,6 +394,8 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
         if (Nyr > NT) return hipErrorInvalidValue;
         // planes per workgroup as in the single-problem kernel (~256 columns), the remaining threads become row slices (>= 8 rows each)
         g.ppb[p] = std::max(1, std::min(256, NT) / Nyr);
+        // few planes (the dD x dD planes of S): fewer planes per workgroup so that the launch still has a few hundred of them
+        while (g.ppb[p] > 1 && (q.planes + g.ppb[p] - 1) / g.ppb[p] < 256) g.ppb[p] = (g.ppb[p] + 1) / 2;
         int S = std::max(1, NT / (g.ppb[p] * Nyr));
         while (S > 1 && q.Nx / S < 8) --S;
         g.rows[p] = S;
@@ -419,6 +421,23 @@ static bool pruned_group_ok(const PrunedGroup& g, const float2* tw, int Nk, int 
         if (q.planes <= 0 || !pruned_supported(Nk, Nl, q.Nx, q.Ny) || q.Ny / 2 + 1 > 256) return false;   // 256-thread workgroups: one thread per column
     }
     return true;
+}
+
+static bool taps_group_ok(const PrunedGroup& g, const float2* tw)
+{
+    if (g.n < 1 || g.n > 8 || !tw) return false;
+    for (int p = 0; p < g.n; ++p) {
+        const PrunedProb& q = g.q[p];
+        if (q.planes <= 0 || q.Nx > TW_N || q.Ny > TW_N || (TW_N % q.Nx) || (TW_N % q.Ny) || q.Ny / 2 + 1 > 256) return false;
+    }
+    return true;
+}
+hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st)
+{
+    if (!taps_group_ok(g, tw)) return hipErrorInvalidValue;
+    if (T == 5) return run_kgrad_group<5, 5>(g, tw, st);
+    if (T == 9) return run_kgrad_group<9, 9>(g, tw, st);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)

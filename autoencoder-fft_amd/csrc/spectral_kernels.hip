@@ -913,7 +913,7 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
                                                         const float2* __restrict__ F, const float* __restrict__ b,
                                                         float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
-                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO)
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO, float* es_out)
 {
     float* esf = reinterpret_cast<float*>(es);
     for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
@@ -927,9 +927,10 @@ __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, con
     }
     __syncthreads();
     const float den = Norm * (float)B;
+    if (blk == 0 && es_out) for (int d = threadIdx.x; d < 2 * dD; d += 256) es_out[d] = esf[d];
     if (blk < fix_blocks) {
         const int t = blk * 256 + threadIdx.x;
-        if (t < dD * dM) {
+        if (t < dD * dM && df) {
             const int d = t / dM, m = t - d * dM;
             const float2 e = es[d];
             const float bb = b[m] * norm;
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float2* __restrict
                                                         int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks)
 {
     extern __shared__ float2 es[];
-    bias_grad_body(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks, blockIdx.x, es, P);
+    bias_grad_body(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks, blockIdx.x, es, P, nullptr);
 }
 
 __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGroup g)
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGrou
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const BiasGradArgs& a = g.a[p];
-    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es, a.PO);
+    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es, a.PO, a.es_out);
 }
 
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st)

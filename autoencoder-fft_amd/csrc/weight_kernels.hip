@@ -1,0 +1,130 @@
+// Weight-side algebra of the training step in the COORDINATE domain of the Nk x Nl kernels (gfx950).
+//
+// The kernel spectra are 25-term trigonometric sums, F[d][m][bin] = sum_{k,l} f[d][m][k][l] e^{-i th_kl(bin)}, so the
+// reference's frequency-domain weight gradient (gradient_k_io, fft_backproplib.cu:395-475, then C2R and shrink_k,
+// :1219-1226)
+//     g_c[m][d][k][l] = sum_bin w Re( e^{+i th_kl} * sum_d1 conj(F[d1][m]) S[d1][d] ) / (Norm B)
+// factors through Q[a][b][tau] = sum_bin w Re( S[a][b][bin] e^{+i th_tau(bin)} ), the pruned inverse transform of the
+// dD x dD planes of S on the (2Nk-1) x (2Nl-1) offsets tau = kl + k'l':
+//     g_c[m][d][kl] = sum_d1 sum_k'l' f[d1][m][k'l'] Q[d1][d][kl + k'l'] / (Norm B)
+//     g_f[d][m][kl] = ( sum_d1 sum_k'l' c[m][d1][k'l'] Q[d][d1][kl + k'l'] + Re es[d] b[m] Nx Ny ) / (Norm B)
+// (same sums, re-associated: float32 rounding only).  The dM*dD-plane gradient spectra dc|df (64 MB written and read
+// back per step at cfg3) never exist.
+#include "internal.h"
+#include <algorithm>
+
+namespace aefft {
+
+// Workgroup = (which gradient, fixed inner channel a, tile of TM outer channels).  For g_f the Q rows Q[a][d1][.] and for g_c
+// the Q columns Q[d1][a][.] (dD x T*T floats) are staged in LDS once, with the tile's weights.  Thread <-> (m in tile, tap
+// row k) owns the NK outputs g[m][a][k][0..NK): per (d1, k2) it reads one weight row (NK floats) and one Q row (T floats)
+// for NK*NK FMAs (a 1-D valid correlation in registers), i.e. ~0.5 LDS reads per FMA instead of 2.
+// Blocks of a problem: [0, dD*mt) -> g_c, [dD*mt, 2*dD*mt) -> g_f, mt = ceil(dM/TM).
+template <int NK>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
+{
+    constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, SL = 4, TM = 256 / (NK * SL);    // 12 outer channels x 4 d1 slices per workgroup for 5x5
+    extern __shared__ float sh[];                       // Qs[dD][TT] | ws[dD][TM][KK] | red[256][NK]
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const WgradProb& q = g.q[p];
+    const int dM = q.dM, dD = q.dD;
+    const int mt = (dM + TM - 1) / TM;
+    int blk = blockIdx.x - g.start[p];
+    const bool isf = blk >= dD * mt;
+    if (isf) blk -= dD * mt;
+    const int a = blk / mt, m0 = (blk - a * mt) * TM;
+    float* Qs = sh;
+    float* ws = sh + dD * TT;
+    float* red = ws + dD * TM * KK;
+    // staging in batches of 8 independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
+    // one memory round trip per element otherwise)
+    for (int t0 = 0; t0 < dD * TT; t0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
+            const int d1 = t / TT, r = t - d1 * TT;
+            v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
+    }
+    for (int t0 = 0; t0 < dD * TM * KK; t0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TM * KK - 1);
+            const int d1 = t / (TM * KK), rem = t - d1 * (TM * KK);
+            const int m2 = min(m0 + rem / KK, dM - 1), r = rem % KK;
+            v[u] = isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = v[u]; }
+    }
+    __syncthreads();
+    const int s = threadIdx.x / (TM * NK), rem = threadIdx.x - s * (TM * NK);
+    const int ml = rem / NK, k = rem - ml * NK;
+    const int m = m0 + ml;
+    float acc[NK];
+#pragma unroll
+    for (int l = 0; l < NK; ++l) acc[l] = 0.f;
+    if (s < SL && m < dM) {
+        for (int d1 = s; d1 < dD; d1 += SL) {
+            const float* wb = ws + (d1 * TM + ml) * KK;
+            const float* Qb = Qs + d1 * TT + k * T;
+#pragma unroll
+            for (int k2 = 0; k2 < NK; ++k2) {
+                float w[NK], qr[T];
+#pragma unroll
+                for (int l2 = 0; l2 < NK; ++l2) w[l2] = wb[k2 * NK + l2];
+#pragma unroll
+                for (int t = 0; t < T; ++t) qr[t] = Qb[k2 * T + t];
+#pragma unroll
+                for (int l2 = 0; l2 < NK; ++l2)
+#pragma unroll
+                    for (int l = 0; l < NK; ++l) acc[l] = fmaf(w[l2], qr[l + l2], acc[l]);
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < NK; ++l) red[threadIdx.x * NK + l] = acc[l];
+    __syncthreads();
+    if (s != 0 || m >= dM) return;
+#pragma unroll
+    for (int l = 0; l < NK; ++l) {
+        float v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < SL; ++s2) v += red[(s2 * (TM * NK) + rem) * NK + l];     // slice order: deterministic
+        acc[l] = v;
+    }
+    const float bias = isf ? q.es[2 * a] * q.b[m] * q.norm : 0.f;                    // the b0 term of fft.cu:448-455 at the DC bin
+    float* dst = isf ? q.gf + ((long)a * dM + m) * KK + k * NK : q.gc + ((long)m * dD + a) * KK + k * NK;
+#pragma unroll
+    for (int l = 0; l < NK; ++l) dst[l] = (acc[l] + bias) * q.inv_den;
+}
+
+hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8 || (Nk != 3 && Nk != 5)) return hipErrorInvalidValue;
+    const int KK = Nk * Nk, TT = (2 * Nk - 1) * (2 * Nk - 1), TM = 256 / (Nk * 4);
+    int total = 0; size_t lds = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const WgradProb& q = g.q[i];
+        g.start[i] = total; total += 2 * q.dD * ((q.dM + TM - 1) / TM);
+        lds = std::max(lds, sizeof(float) * ((size_t)q.dD * TT + (size_t)q.dD * TM * KK + 256 * Nk));
+    }
+    g.start[g.n] = total;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = Nk == 3 ? hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (Nk == 3) wgrad_taps_kernel<3><<<dim3(total), 256, lds, st>>>(g);
+    else wgrad_taps_kernel<5><<<dim3(total), 256, lds, st>>>(g);
+    return hipGetLastError();
+}
+
+}  // namespace aefft
