@@ -907,7 +907,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             n->NxC = qc.Nx; n->NyC = qc.Ny; n->Pc = qc.P;
             for (int l = 0; l < n->L && rc == AEFFT_OK; ++l) {
                 Pair& q = n->pr[l];
-                if (l == n->L - 1) q.Oc = q.O;
+                if (q.P == n->Pc) q.Oc = q.O;            // already on the coarsest grid: nothing to compact
                 else rc = net_alloc_t(n, &q.Oc, (size_t)n->B * q.dD * n->Pc);
                 if (rc == AEFFT_OK && q.Nk == q.Nl && (q.Nk == 3 || q.Nk == 5)) {
                     const size_t tt = (size_t)(2 * q.Nk - 1) * (2 * q.Nk - 1);
@@ -1078,7 +1078,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         q.O_stale = false;
         if (l == L - 1) { RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny)); continue; }
         const Pair& in = n->pr[l + 1];
-        if (compact) {
+        if (compact && q.P != n->Pc) {
             // Up-sampled spectra are zero outside the image of the coarsest grid, and conv_k maps zero to zero (the bias sits on
             // the DC bin, inside it): every decoder output lives on those Pc bins.  The training step computes and stores only them:
             //   Oc_l[b][d][s] = sum_m F_l[d][m][map_l(s)] * Oc_{l+1}[b][m][s] / dD + p[d] Nx Ny [s == 0]
@@ -1314,7 +1314,6 @@ static int grads_grouped(aefft_net* n)
     for (int l = 0; l < n->L && same; ++l) {
         const Pair& q = n->pr[l];
         same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
-        same = same && q.Ny / 2 + 1 <= 256;
     }
     static const char* noq = getenv("AEFFT_NOQPATH");
     bool qpath = same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
@@ -1435,7 +1434,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
         const Pair& q = n->pr[l];
-        grouped_w = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny) && q.Ny / 2 + 1 <= 256;
+        grouped_w = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
     }
     if (grouped_w) {
         UpdateGroup ug{};

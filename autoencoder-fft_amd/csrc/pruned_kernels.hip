@@ -380,7 +380,10 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
         lds = std::max(lds, kspec_lds(g.rows[p], NK));
     }
     g.start[g.n] = total;
-    kspec_group_kernel<NK, NL><<<dim3(total), 256, lds, st>>>(g, tw);
+    int threads = 256;                                    // one thread per (plane in group, column)
+    for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
+    if (threads > 320) return hipErrorInvalidValue;
+    kspec_group_kernel<NK, NL><<<dim3(total), threads, lds, st>>>(g, tw);
     return hipGetLastError();
 }
 
@@ -418,7 +421,7 @@ static bool pruned_group_ok(const PrunedGroup& g, const float2* tw, int Nk, int 
     if (g.n < 1 || g.n > 8 || !tw) return false;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
-        if (q.planes <= 0 || !pruned_supported(Nk, Nl, q.Nx, q.Ny) || q.Ny / 2 + 1 > 256) return false;   // 256-thread workgroups: one thread per column
+        if (q.planes <= 0 || !pruned_supported(Nk, Nl, q.Nx, q.Ny)) return false;
     }
     return true;
 }
@@ -428,7 +431,7 @@ static bool taps_group_ok(const PrunedGroup& g, const float2* tw)
     if (g.n < 1 || g.n > 8 || !tw) return false;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
-        if (q.planes <= 0 || q.Nx > TW_N || q.Ny > TW_N || (TW_N % q.Nx) || (TW_N % q.Ny) || q.Ny / 2 + 1 > 256) return false;
+        if (q.planes <= 0 || q.Nx > TW_N || q.Ny > TW_N || (TW_N % q.Nx) || (TW_N % q.Ny) || q.Ny / 2 + 1 > 320) return false;
     }
     return true;
 }
