@@ -369,7 +369,7 @@ static int do_contract(aefft_ctx* ctx, const Contract& q);
 // n independent contractions of class cls (see ContractN) in one launch; falls back to one launch each
 static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, int cls)
 {
-    static const char* nogroup = getenv("AEFFT_NOGROUP");
+    const char* nogroup = getenv("AEFFT_NOGROUP");
     if (n <= 8 && n > 1 && !nogroup) {
         ContractN g{};
         double bytes = 0;
@@ -1052,11 +1052,11 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     for (int l = 0; l < L; ++l) {
         Pair& q = n->pr[l];
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
-        static const char* nofuse = getenv("AEFFT_NOFUSECROP");
+        const char* nofuse = getenv("AEFFT_NOFUSECROP");
         const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !nofuse;
         q.H_stale = false;
         if (fuse && lazy) {
-            static const char* nolazy = getenv("AEFFT_NOLAZY");
+            const char* nolazy = getenv("AEFFT_NOLAZY");
             const Pair& nx = n->pr[l + 1];
             bool done = false;
             if (!nolazy) RET_IF(do_conv_pooled(ctx, q.X, q.C, q.b, nx.X, B, q.dM, q.dD, q.Nx, q.Ny, nx.Nx, nx.Ny, &done));
@@ -1071,7 +1071,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     // decoder (:1356-1361): conv then zero-pad up-sampling.  The up-sampled tensor is never stored: the next
     // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
-    static const char* nocompact = getenv("AEFFT_NOCOMPACT");
+    const char* nocompact = getenv("AEFFT_NOCOMPACT");
     bool compact = lazy && n->compact && !nocompact && L > 1;
     for (int l = L - 1; l >= 0; --l) {
         Pair& q = n->pr[l];
@@ -1110,7 +1110,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
         Pair& q = n->pr[0];
-        static const char* nooverlap = getenv("AEFFT_NOOVERLAP");
+        const char* nooverlap = getenv("AEFFT_NOOVERLAP");
         const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
         if (async) {
             // training step: nothing downstream reads the reconstruction, so its (bandwidth-bound) inverse FFT runs on a side
@@ -1309,13 +1309,13 @@ static int grads_grouped(aefft_net* n)
         RET_IF(do_contract_group(ctx, qs, m, m, 1));
     }
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
-    static const char* nogroup = getenv("AEFFT_NOGROUP");
+    const char* nogroup = getenv("AEFFT_NOGROUP");
     bool same = n->L > 1 && n->L <= 8 && !nogroup;
     for (int l = 0; l < n->L && same; ++l) {
         const Pair& q = n->pr[l];
         same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
     }
-    static const char* noq = getenv("AEFFT_NOQPATH");
+    const char* noq = getenv("AEFFT_NOQPATH");
     bool qpath = same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
     for (int l = 0; l < n->L && qpath; ++l) qpath = n->pr[l].Q != nullptr;
     if (same) {
@@ -1409,7 +1409,7 @@ static int grads_grouped(aefft_net* n)
 static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
 {
     aefft_ctx* ctx = n->ctx;
-    static const char* nofuse = getenv("AEFFT_NOFUSEMSE");
+    const char* nofuse = getenv("AEFFT_NOFUSEMSE");
     if (!nofuse && q.dD >= 2 && n->B >= 2) {
         RET_IF(do_contract(ctx, mk_G(q.F, q.C, q.S, q.dM, q.dD, q.P)));
         const Contract m = mk_gmse(q.S, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
@@ -1430,7 +1430,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
 static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gscale, float* mse_d)
 {
     aefft_ctx* ctx = n->ctx;
-    static const char* nogroup1 = getenv("AEFFT_NOGROUP");
+    const char* nogroup1 = getenv("AEFFT_NOGROUP");
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
         const Pair& q = n->pr[l];
@@ -1477,8 +1477,8 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     // post-update MSE (fft_backproplib.cu:1460-1463): G = F.C of every eligible pair in one launch, then every pair's pass
     // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
     {
-        static const char* nofuse = getenv("AEFFT_NOFUSEMSE");
-        static const char* nogroup = getenv("AEFFT_NOGROUP");
+        const char* nofuse = getenv("AEFFT_NOFUSEMSE");
+        const char* nogroup = getenv("AEFFT_NOGROUP");
         Contract gq[8], mq[8];
         int m = 0;
         std::vector<int> rest;
@@ -1492,7 +1492,43 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         bool grouped = false;
         if (m > 1) {
-            RET_IF(do_contract_group(ctx, gq, m, m, 0));
+            // G = F.C/(dM dD).  HBM-sized kernel spectra (no pooling): as the spectrum of the (2Nk-1)^2-tap kernel f (*) c
+            // (weight_kernels.hip), which reads the kernels and writes dD*dD planes instead of reading all 2*dM*dD planes of C|F;
+            // cache-sized ones: as a per-bin contraction of the spectra (measured faster there).
+            const char* noq = getenv("AEFFT_NOQPATH");
+            double cf_bytes = 0;
+            for (int l = 0; l < n->L; ++l) cf_bytes += 2.0 * n->pr[l].dM * n->pr[l].dD * n->pr[l].P * 8.0;
+            bool gtaps = !noq && (cf_bytes > 256e6 || getenv("AEFFT_GTAPS")) && m == n->L && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
+            for (int l = 0; l < n->L && gtaps; ++l) { const Pair& q = n->pr[l]; gtaps = q.Q && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl; }
+            if (gtaps) {
+                GspGroup gg{};
+                PrunedGroup pg{};
+                const int T = 2 * n->pr[0].Nk - 1;
+                double gbytes = 0, kbytes = 0;
+                for (int l = 0; l < n->L; ++l) {
+                    Pair& q = n->pr[l];
+                    gg.q[l] = GspProb{q.c, q.f, q.Q, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};     // Q is dead after the weight gradients: reused for gsp
+                    pg.q[l] = PrunedProb{q.Q, q.S, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
+                    gbytes += (2.0 * q.dM * q.dD * q.Nk * q.Nl + (double)q.dD * q.dD * T * T) * 4.0;
+                    kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
+                }
+                gg.n = pg.n = n->L;
+                hipError_t e;
+                {
+                    Bracket br(ctx, KID_WGRAD, gbytes);
+                    e = launch_gspatial_group(gg, n->pr[0].Nk, ctx->cur);
+                }
+                if (e == hipSuccess) {
+                    Bracket br(ctx, KID_KSPEC, kbytes);
+                    e = launch_kspec_group_taps(pg, ctx->tw, T, ctx->cur);
+                }
+                if (e != hipSuccess) {
+                    if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G(taps)", e);
+                    (void)hipGetLastError();
+                    gtaps = false;
+                }
+            }
+            if (!gtaps) RET_IF(do_contract_group(ctx, gq, m, m, 0));
             ContractN g{};
             double bytes = 0;
             for (int i = 0; i < m; ++i) { g.q[i] = mq[i]; bytes += ((double)mq[i].R * mq[i].K + 2.0 * mq[i].K * mq[i].C) * mq[i].P * 8.0; }

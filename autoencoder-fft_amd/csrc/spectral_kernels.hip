@@ -500,7 +500,7 @@ template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_gr
     return hipGetLastError();
 }
 
-static bool use_mfma() { static const char* off = getenv("AEFFT_NOMFMA"); return !off; }
+static bool use_mfma() { return !getenv("AEFFT_NOMFMA"); }   // (read per call: the tests switch code paths inside one process)
 
 hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st)
 {
@@ -750,7 +750,7 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
     if (waves(vec, tr, tc) < 1024 && vec == 2) vec = 1;
     static const char* tile = getenv("AEFFT_TILE");       // dev switch: "v,r,c"
     if (tile) { int v_, r_, c_; if (sscanf(tile, "%d,%d,%d", &v_, &r_, &c_) == 3) { if (even || v_ == 1) vec = v_; tr = std::min(r_, tr == 1 ? 1 : (Rmin >= r_ ? r_ : tr)); tc = std::min(c_, Cmin >= c_ ? c_ : tc); } }
-    static const char* nofast = getenv("AEFFT_NOFAST");
+    const char* nofast = getenv("AEFFT_NOFAST");
     const int fc = nofast ? -1 : contract_fast_class(qq);
     if (fc >= 0 && tr >= 2 && tc >= 2) {
         // split-K when even the shrunk tiles leave the chip short of waves and the K chain is long

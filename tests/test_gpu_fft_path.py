@@ -198,10 +198,19 @@ def test_golden_forward_and_bursts(ctx, tag, D, N, maps, Nk, s):
             net.close()
 
 
+# Every alternative code path of the training step must give the oracle's numbers: the library reads these switches per call.
+STEP_PATHS = ["", "AEFFT_GTAPS", "AEFFT_NOQPATH", "AEFFT_NOCOMPACT", "AEFFT_NOLAZY", "AEFFT_NOGROUP", "AEFFT_NOFUSEMSE",
+              "AEFFT_NOMFMA", "AEFFT_NOOVERLAP", "AEFFT_NOFUSECROP"]
+
+
+@pytest.mark.parametrize("path", STEP_PATHS)
 @pytest.mark.parametrize("B", [1, 3])
-def test_step_equals_oracle_batch_iteration(ctx, B):
+def test_step_equals_oracle_batch_iteration(ctx, B, path, monkeypatch):
     """aefft_net_step_grad / step_apply == oracle batch_train_iter for every pair (build-defined
-    batch mean); B=1 is the reference loop body."""
+    batch mean); B=1 is the reference loop body.  `path` disables one optimisation
+    (or forces one that the small test shapes would not choose) so that its fallback is exercised too."""
+    if path:
+        monkeypatch.setenv(path, "1")
     rng = np.random.default_rng(77 + B)
     D, N, maps, Nk, s = 3, 32, [4, 6], 5, 2
     L = len(maps)
