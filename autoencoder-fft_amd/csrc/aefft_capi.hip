@@ -1357,15 +1357,16 @@ static int grads_grouped(aefft_net* n)
                 RET_IF(do_contract_group(ctx, qs, 2 * m, m, 2));
             }
         }
-        {
+        if (!qpath) {
             Bracket br(ctx, KID_BIASGRAD, bbytes);
             hipError_t e = launch_bias_grad_group(bg, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "bias_grad(group)", e);
         }
         hipError_t e;
         {
-            Bracket br(ctx, KID_KGRAD, kbytes);
-            e = qpath ? launch_kgrad_group_taps(pg, ctx->tw, T, ctx->cur) : launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+            Bracket br(ctx, KID_KGRAD, kbytes + (qpath ? bbytes : 0.0));
+            e = qpath ? launch_kgrad_group_taps(pg, ctx->tw, T, ctx->cur, &bg)      // (the DC-bin terms ride along as extra workgroups)
+                      : launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
         }
         if (e == hipSuccess && qpath) {
             Bracket br(ctx, KID_WGRAD, wbytes);

@@ -78,4 +78,53 @@ template <> struct BufLoad<2> {
 };
 
 
+// DC-bin terms of gradient_k_io (see bias_grad_kernel, spectral_kernels.hip)
+__device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
+                                                        const float2* __restrict__ F, const float* __restrict__ b,
+                                                        float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO, float* es_out)
+{
+    // written for 256 threads; in a larger workgroup (the fused kgrad launch) the extra threads only take part in the barriers
+    const bool wk = threadIdx.x < 256;
+    float* esf = reinterpret_cast<float*>(es);
+    if (wk) for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
+    __syncthreads();
+    // (frame, channel) pairs spread over the threads so the B*dD DC-bin loads are all in flight at once
+    if (wk) for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
+        const int d = idx % dD;
+        const float2 o = O[(long)idx * PO], t = T[(long)idx * P];
+        atomicAdd(&esf[2 * d], o.x - t.x);
+        atomicAdd(&esf[2 * d + 1], o.y - t.y);
+    }
+    __syncthreads();
+    if (!wk) return;
+    const float den = Norm * (float)B;
+    if (blk == 0 && es_out) for (int d = threadIdx.x; d < 2 * dD; d += 256) es_out[d] = esf[d];
+    if (blk < fix_blocks) {
+        const int t = blk * 256 + threadIdx.x;
+        if (t < dD * dM && df) {
+            const int d = t / dM, m = t - d * dM;
+            const float2 e = es[d];
+            const float bb = b[m] * norm;
+            float2* p = df + ((long)d * dM + m) * P;
+            float2 v = *p;
+            v.x += e.x * bb / den; v.y += e.y * bb / den;
+            *p = v;
+        }
+        if (t < dD) dp[t] = es[t].x * norm / den;
+        return;
+    }
+    // db: one wave per output map m, lanes over d1
+    const int m = (blk - fix_blocks) * 4 + (threadIdx.x >> 6);
+    if (m >= dM) return;
+    float s = 0.f;
+    for (int d1 = threadIdx.x & 63; d1 < dD; d1 += 64) {
+        const float2 e = es[d1], f = F[((long)d1 * dM + m) * P];
+        s += e.x * f.x + e.y * f.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) db[m] = s * norm / den;
+}
+
 }  // namespace aefft

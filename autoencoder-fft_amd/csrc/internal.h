@@ -99,7 +99,7 @@ struct PrunedGroup { PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblo
 hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 // the inverse transform on a T x T support with T = 5 or 9 (the offsets kl + k'l' of 3x3 / 5x5 kernels, weight_kernels.hip)
-hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);
+hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias = nullptr /* fused: the DC-bin terms as extra workgroups */);
 hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);
 
 // ---- weight_kernels.hip ----------------------------------------------------------------

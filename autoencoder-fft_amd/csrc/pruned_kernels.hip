@@ -16,6 +16,7 @@
 // Row and column phase tables (Nx*Nk and Nyr*Nl complex) are built per workgroup in LDS from the
 // global twiddle table, so each bin costs one 8-byte global access plus LDS reads.
 #include "internal.h"
+#include "device_util.h"
 #include <algorithm>
 
 namespace aefft {
@@ -258,26 +259,52 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         }
     }
     __syncthreads();
-    // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ), columns in order
-    for (int it = threadIdx.x; it < ppb * NK * NL; it += NT) {
-        const int p2 = it / (NK * NL), kl = it - p2 * (NK * NL);
+    // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ): the columns of a plane are split over JS threads per output
+    // (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums combined in slice order
+    const int nout = ppb * NK * NL;
+    int JS = NT / nout;
+    if (JS < 1) JS = 1;
+    if (JS > 16) JS = 16;
+    const int jlen = (Nyr + JS - 1) / JS;
+    float* part = tim + NK * TS;                          // [nout][JS], after the t arrays
+    for (int it = threadIdx.x; it < nout * JS; it += NT) {
+        const int o = it / JS, js = it - o * JS;
+        const int p2 = o / (NK * NL), kl = o - p2 * (NK * NL);
         const int k = kl / NL, l = kl - k * NL;
-        const long pln = (long)bx * ppb + p2;
-        if (pln >= planes) continue;
         float a = 0.f;
-        for (int jj = 0; jj < Nyr; ++jj) {
+        const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
+        for (int jj = j0; jj < j1; ++jj) {
             const float2 cp = colph[jj * NL + l];
             const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
             a += wj * (tre[k * TS + p2 * Nyr + jj] * cp.x - tim[k * TS + p2 * Nyr + jj] * cp.y);
         }
+        part[it] = a;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += NT) {
+        const int p2 = o / (NK * NL), kl = o - p2 * (NK * NL);
+        const long pln = (long)bx * ppb + p2;
+        if (pln >= planes) continue;
+        float a = 0.f;
+        for (int js = 0; js < JS; ++js) a += part[o * JS + js];
         g[pln * (NK * NL) + kl] = a * scale;
     }
 }
 
 template <int NK, int NL, int NT>
-__global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, const float2* __restrict__ tw)
+__global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const BiasGradGroup bg)
 {
     extern __shared__ float2 lds[];
+    if ((int)blockIdx.x >= g.start[g.n]) {
+        // trailing workgroups: the independent DC-bin terms (db, dp, es) of every pair ride along instead of costing a launch
+        const int blk = blockIdx.x - g.start[g.n];
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (i < bg.n && blk >= bg.start[i]) p = i;
+        const BiasGradArgs& a = bg.a[p];
+        bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, bg.fix[p], blk - bg.start[p], lds, a.PO, a.es_out);
+        return;
+    }
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
@@ -387,7 +414,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     return hipGetLastError();
 }
 
-template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st)
+template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st, BiasGradGroup* bgp = nullptr)
 {
     constexpr int NT = 1024;
     int total = 0; size_t lds = 0;
@@ -404,7 +431,7 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
         g.rows[p] = S;
         g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
         g.start[p] = total; total += g.pblocks[p];
-        lds = std::max(lds, sizeof(float2) * ((size_t)q.Nx * NK + (size_t)Nyr * NL) + sizeof(float) * 2 * NK * (NT + 1));
+        lds = std::max(lds, sizeof(float2) * ((size_t)q.Nx * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + (size_t)std::max(NT, g.ppb[p] * NK * NL)));
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -412,7 +439,21 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kgrad_group_kernel<NK, NL, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    kgrad_group_kernel<NK, NL, NT><<<dim3(total), NT, lds, st>>>(g, tw);
+    BiasGradGroup bg{};
+    int extra = 0;
+    if (bgp) {
+        int dDmax = 0;
+        for (int i = 0; i < bgp->n; ++i) {
+            const BiasGradArgs& a = bgp->a[i];
+            bgp->fix[i] = (a.dM * a.dD + 255) / 256;
+            bgp->start[i] = extra; extra += bgp->fix[i] + (a.dM + 3) / 4;
+            dDmax = std::max(dDmax, a.dD);
+        }
+        bgp->start[bgp->n] = extra;
+        lds = std::max(lds, sizeof(float2) * (size_t)dDmax);
+        bg = *bgp;
+    }
+    kgrad_group_kernel<NK, NL, NT><<<dim3(total + extra), NT, lds, st>>>(g, tw, bg);
     return hipGetLastError();
 }
 
@@ -442,11 +483,11 @@ hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
     if (T == 9) return run_kspec_group<9, 9>(g, tw, st);
     return hipErrorInvalidValue;
 }
-hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st)
+hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias)
 {
-    if (!taps_group_ok(g, tw)) return hipErrorInvalidValue;
-    if (T == 5) return run_kgrad_group<5, 5>(g, tw, st);
-    if (T == 9) return run_kgrad_group<9, 9>(g, tw, st);
+    if (!taps_group_ok(g, tw) || (bias && (bias->n < 1 || bias->n > 8))) return hipErrorInvalidValue;
+    if (T == 5) return run_kgrad_group<5, 5>(g, tw, st, bias);
+    if (T == 9) return run_kgrad_group<9, 9>(g, tw, st, bias);
     return hipErrorInvalidValue;
 }
 
