@@ -785,6 +785,8 @@ struct Pair {
     float2 *C, *F;
     bool spectra_valid;
     bool H_stale = false;    // the last (lazy) forward produced only the pooled part of H: recompute before reading H
+    bool G_valid = false;    // S holds G = F.C/(dM dD) of the CURRENT weights and beta its DC bias (left there by aefft_net_step_apply)
+    float* beta = nullptr;   // [dD]
     float* Q = nullptr;      // [dD][dD][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip)
     float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
     bool O_stale = false;    // the last (lazy) forward produced Oc only: expand before reading O
@@ -907,6 +909,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             n->NxC = qc.Nx; n->NyC = qc.Ny; n->Pc = qc.P;
             for (int l = 0; l < n->L && rc == AEFFT_OK; ++l) {
                 Pair& q = n->pr[l];
+                if (rc == AEFFT_OK) rc = net_alloc_t(n, &q.beta, (size_t)q.dD);
                 if (q.P == n->Pc) q.Oc = q.O;            // already on the coarsest grid: nothing to compact
                 else rc = net_alloc_t(n, &q.Oc, (size_t)n->B * q.dD * n->Pc);
                 if (rc == AEFFT_OK && q.Nk == q.Nl && (q.Nk == 3 || q.Nk == 5)) {
@@ -963,7 +966,7 @@ extern "C" int aefft_net_set_pair(aefft_net* n, int l, const float* c_h, const f
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be pageable / reused by the caller
-    q.spectra_valid = false;
+    q.spectra_valid = false; q.G_valid = false;
     return AEFFT_OK;
 }
 
@@ -1033,7 +1036,7 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    q.spectra_valid = true;
+    q.spectra_valid = true; q.G_valid = false;
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.C), q.c, q.dM, q.dD, q.Nk, q.Nl, q.Nx, q.Ny));
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.F), q.f, q.dD, q.dM, q.Nk, q.Nl, q.Nx, q.Ny));
     return AEFFT_OK;
@@ -1055,6 +1058,13 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         const char* nofuse = getenv("AEFFT_NOFUSECROP");
         const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !nofuse;
         q.H_stale = false;
+        if (lazy && l == L - 1 && q.G_valid && !getenv("AEFFT_NOGFWD")) {
+            // innermost pair of a training step: its hidden layer feeds only its own decoder conv, and the previous step left
+            // the collapsed operator of the CURRENT weights behind (G = F.C/(dM dD) in S, DC bias in beta): O = G X + beta below,
+            // a quarter of the arithmetic and bytes of conv_k o conv_k, no H.
+            q.H_stale = true;
+            continue;
+        }
         if (fuse && lazy) {
             const char* nolazy = getenv("AEFFT_NOLAZY");
             const Pair& nx = n->pr[l + 1];
@@ -1076,7 +1086,18 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     for (int l = L - 1; l >= 0; --l) {
         Pair& q = n->pr[l];
         q.O_stale = false;
-        if (l == L - 1) { RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny)); continue; }
+        if (l == L - 1) {
+            if (q.H_stale) {                       // (set above: G route)
+                Contract k{};
+                k.A = q.S; k.a_r = (long)q.dD * q.P; k.a_k = q.P;
+                k.B = q.X; k.b_k = q.P; k.b_c = (long)q.dD * q.P;
+                k.Out = q.O; k.o_r = q.P; k.o_c = (long)q.dD * q.P;
+                k.R = q.dD; k.C = B; k.K = q.dD; k.P = q.P;
+                k.bias = q.beta; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
+                RET_IF(do_contract(ctx, k));
+            } else RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
+            continue;
+        }
         const Pair& in = n->pr[l + 1];
         if (compact && q.P != n->Pc) {
             // Up-sampled spectra are zero outside the image of the coarsest grid, and conv_k maps zero to zero (the bias sits on
@@ -1291,7 +1312,7 @@ static int grads_grouped(aefft_net* n)
     aefft_ctx* ctx = n->ctx;
     Contract qs[8];
     bool comp = false;
-    for (int l = 0; l < n->L; ++l) comp = comp || n->pr[l].O_stale;
+    for (int l = 0; l < n->L; ++l) { comp = comp || n->pr[l].O_stale; n->pr[l].G_valid = false; }      // S is about to overwrite G
     for (int l0 = 0; l0 < n->L; l0 += 4) {
         const int m = std::min(4, n->L - l0);
         if (!comp) {
@@ -1407,8 +1428,9 @@ static int grads_grouped(aefft_net* n)
 // re-forward's H and O again (the next forward overwrites them), so they are not materialised: G = F.C per bin
 // (into the dead S workspace), then one pass over X with the MSE epilogue.  Falls back to conv, conv, diff_mse
 // for shapes the lean kernel does not serve (dD == 1 or B == 1).
-static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
+static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_in_S = nullptr)
 {
+    if (g_left_in_S) *g_left_in_S = false;
     aefft_ctx* ctx = n->ctx;
     const char* nofuse = getenv("AEFFT_NOFUSEMSE");
     if (!nofuse && q.dD >= 2 && n->B >= 2) {
@@ -1419,7 +1441,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots)
             Bracket br(ctx, KID_CONTRACT, ((double)m.R * m.K + 2.0 * m.K * m.C) * m.P * 8.0);
             e = launch_contract(m, ctx->cur);
         }
-        if (e == hipSuccess) return AEFFT_OK;
+        if (e == hipSuccess) { if (g_left_in_S) *g_left_in_S = true; return AEFFT_OK; }
         if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(mse)", e);
         (void)hipGetLastError();
     }
@@ -1477,6 +1499,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     }
     // post-update MSE (fft_backproplib.cu:1460-1463): G = F.C of every eligible pair in one launch, then every pair's pass
     // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
+    std::vector<char> g_in_S(n->L, 0);       // pair l: S holds G of the updated weights after this call
     {
         const char* nofuse = getenv("AEFFT_NOFUSEMSE");
         const char* nogroup = getenv("AEFFT_NOGROUP");
@@ -1545,12 +1568,18 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         for (int l = 0; l < n->L; ++l) {
             const bool in_group = grouped && std::find(rest.begin(), rest.end(), l) == rest.end();
-            if (!in_group) RET_IF(reforward_mse(n, n->pr[l], n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE));
+            bool left = in_group;
+            if (!in_group) RET_IF(reforward_mse(n, n->pr[l], n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, &left));
+            g_in_S[l] = left;
         }
     }
     {
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur);     // also the copy-out to mse_d
+        Pair& ql = n->pr[n->L - 1];
+        BetaArgs ba{ql.beta, ql.F, ql.b, ql.p, ql.dM, ql.dD, ql.P};
+        const bool want_beta = g_in_S[n->L - 1] && ql.beta && ql.dD <= 256;
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, want_beta ? &ba : nullptr);     // also the copy-out to mse_d
+        ql.G_valid = want_beta && e == hipSuccess;
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
     }
     return AEFFT_OK;

@@ -62,7 +62,9 @@ struct Contract {
     struct Mse { float* acc; const float2* F; const float* b; const float* p; int dM, Nyr; float nfull, scale, norm; } mse;
 };
 enum { MSE_SLOTS = 256, MSE_SLOT_STRIDE = 16 };
-hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st);
+struct BetaArgs { float* beta; const float2* F; const float *b, *p; int dM, dD; long P; };     // beta == null: off
+hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st,
+                             const BetaArgs* beta = nullptr);
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 // Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):

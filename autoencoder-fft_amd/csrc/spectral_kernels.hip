@@ -910,10 +910,24 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 //   db[m]       = Re( sum_d1 es[d1] * conj(F[d1][m](0,0)) ) * norm / (Norm*B)      (fft_backproplib.cu:432,465)
 //   dp[d]       = Re es[d] * norm / (Norm*B)                                       (:471)
 //   df[d][m](0,0) += es[d] * b[m]*norm / (Norm*B)    -- the b0 term of :448-455 (H' bias at DC)
-// sums (and clears) the slot accumulators of the MSE epilogue: out[l] += sum, copy[l] = out[l]
-__global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, int L)
+// sums (and clears) the slot accumulators of the MSE epilogue: out[l] += sum, copy[l] = out[l].  Optionally also forms the
+// DC-bin bias of the collapsed pair operator O = G X + beta (conv_k o conv_k, fft.cu:183-184 twice):
+//   beta[d'] = p[d'] + sum_m F[d'][m](0,0) b[m] / dD          (times Nx*Ny where it is applied)
+__global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, int L,
+                                                               const BetaArgs ba)
 {
     __shared__ float ws[MSE_SLOTS / 64];
+    __shared__ float bacc[256];
+    if (ba.beta) {
+        for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) bacc[d] = 0.f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ba.dD * ba.dM; i += MSE_SLOTS) {
+            const int d = i / ba.dM, m = i - d * ba.dM;
+            atomicAdd(&bacc[d], ba.F[(long)i * ba.P].x * ba.b[m]);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) ba.beta[d] = ba.p[d] + bacc[d] / (float)ba.dD;
+    }
     for (int l = 0; l < L; ++l) {
         float* s = slots + ((long)l * MSE_SLOTS + threadIdx.x) * MSE_SLOT_STRIDE;
         float v = *s;
@@ -932,9 +946,11 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
     }
 }
 
-hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st)
+hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba)
 {
-    mse_finish_kernel<<<1, MSE_SLOTS, 0, st>>>(slots, out, copy, L);
+    BetaArgs a{};
+    if (ba && ba->dD <= 256) a = *ba;
+    mse_finish_kernel<<<1, MSE_SLOTS, 0, st>>>(slots, out, copy, L, a);
     return hipGetLastError();
 }
 

@@ -255,6 +255,43 @@ def test_step_equals_oracle_batch_iteration(ctx, B, path, monkeypatch):
     net.close()
 
 
+@pytest.mark.parametrize("path", ["", "AEFFT_NOGFWD", "AEFFT_NOCOMPACT", "AEFFT_NOMFMA"])
+def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, monkeypatch):
+    """State carried from one training step to the next (the collapsed operator G of the innermost pair, cached spectra,
+    stale-layer flags) must be invisible: step 2 on a live net == step 1 of a fresh net that starts from the live net's
+    weights and momentum-free... momentum persists across steps, so the comparison is on what does not depend on it:
+    the reconstruction, every layer and the packed gradients of step 2."""
+    if path:
+        monkeypatch.setenv(path, "1")
+    rng = np.random.default_rng(123)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6, 5], 5, 2, 3
+    L = len(maps)
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    dD = D
+    for l, dM in enumerate(maps):
+        _, cw, fw, bw, pw = _pair(rng, dD, dM, 8, Nk, 1)
+        net.set_pair(l, cw, bw, fw, pw); dD = dM
+    x1 = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    x2 = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    r_live = ctx.empty(B, D, N, N)
+    net.step_grad(x1, None); net.step_apply(0.2)
+    weights = [net.get_pair(l) for l in range(L)]
+    net.step_grad(x2, r_live)
+    g_live = host(net.grad_buffer()).copy()
+    layers_live = [host(net.get_layer(l)).copy() for l in range(1, 4 * L + 1)]
+    fresh = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, (cw, bw, fw, pw) in enumerate(weights):
+        fresh.set_pair(l, cw, bw, fw, pw)
+    r_fresh = ctx.empty(B, D, N, N)
+    fresh.step_grad(x2, r_fresh)
+    g_fresh = host(fresh.grad_buffer())
+    assert relerr(host(r_live), host(r_fresh)) < 2e-5
+    assert relerr(g_live, g_fresh) < 5e-5
+    for a, b in zip(layers_live, [host(fresh.get_layer(l)) for l in range(1, 4 * L + 1)]):
+        assert relerr(a, b) < 5e-5
+    net.close(); fresh.close()
+
+
 def test_spectra_store_load_roundtrip(ctx):
     """net_cfreq semantics: store_cfreq / load_cfreq (fft_backproplib.cu:1117-1141)."""
     rng = np.random.default_rng(3)
