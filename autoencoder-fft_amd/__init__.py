@@ -64,6 +64,7 @@ SIGNATURES = {
     "aefft_net_get_layer": (_i, [_vp, _i, _fp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "aefft_net_train_pair": (_i, [_vp, _i, _i, _f, _i, _i, _vp]),
     "aefft_net_step_grad": (_i, [_vp, _fp, _fp]),
+    "aefft_net_set_input_ready": (_i, [_vp, _i]),
     "aefft_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "aefft_net_step_apply": (_i, [_vp, _f, _i, _i, _f, _fp]),
     "aefft_net_reset_momentum": (_i, [_vp]),
@@ -355,6 +356,10 @@ class Net:
         mse = np.zeros(n_iter + 1, np.float32)
         self.ctx.check(self.L.aefft_net_train_pair(self.h, l, n_iter, del0, maxdiff, sym, _hptr(mse)))
         return mse
+
+    def set_input_ready(self, on=True):
+        """Frames given to step_grad are complete when the call is made: their R2C may run ahead on a side stream."""
+        self.ctx.check(self.L.aefft_net_set_input_ready(self.h, 1 if on else 0))
 
     def step_grad(self, frames, recon=None):
         self.ctx.check(self.L.aefft_net_step_grad(self.h, _ptr(frames), _ptr(recon)))

@@ -15,7 +15,7 @@ using namespace aefft;
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_PART = 10, WS_COUNT = 11 };
+enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_PART = 10, WS_MID2 = 11, WS_COUNT = 12 };
 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
@@ -201,12 +201,12 @@ static int chk_size(aefft_ctx* ctx, int Nx, int Ny)
 }
 
 // R2C (+ fused crop to Nxs x Nys).  The two kernels are bracketed separately for profiling.
-static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys)
+static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys, int ws_id = WS_MID)
 {
     RET_IF(chk_size(ctx, Nx, Ny));
     if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
     void* mid;
-    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * fft_mid_elems(planes, Nx, Nys / 2), &mid));
+    RET_IF(ws_get(ctx, ws_id, sizeof(float2) * fft_mid_elems(planes, Nx, Nys / 2), &mid));
     // launch_r2c issues rows then cols; bracket as two launches by splitting the byte accounting:
     // rows: read planes*Nx*Ny*4, write mid; cols: read mid, write out.
     const double b_in = (double)planes * Nx * Ny * 4, b_mid = (double)planes * Nx * (Nys / 2) * 8, b_out = (double)planes * bins(Nxs, Nys) * 8;
@@ -815,6 +815,13 @@ struct aefft_net {
     bool have_forward = false, have_grad = false;
     int NxC = 0, NyC = 0; long Pc = 0;   // grid of the coarsest pair = support of every decoder output
     bool compact = true;                 // the training step may keep decoder outputs on that support only
+    // input prefetch (aefft_net_set_input_ready): second buffer for pair 0's input spectra, end-of-step events, step counter
+    bool input_ready = false;
+    float2* X0alt = nullptr;
+    hipEvent_t ev_end[2] = {nullptr, nullptr}, ev_r2c = nullptr, ev_mid = nullptr;
+    bool ev_mid_valid = false;
+    bool ev_end_valid[2] = {false, false};
+    unsigned long step_no = 0;
     bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
     bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
     // shared scratch sized for the largest pair
@@ -836,6 +843,10 @@ extern "C" void aefft_net_destroy(aefft_net* net)
 {
     if (!net) return;
     (void)hipStreamSynchronize(net->ctx->stream);
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) if (net->ctx->aux[i]) (void)hipStreamSynchronize(net->ctx->aux[i]);
+    for (int i = 0; i < 2; ++i) if (net->ev_end[i]) (void)hipEventDestroy(net->ev_end[i]);
+    if (net->ev_r2c) (void)hipEventDestroy(net->ev_r2c);
+    if (net->ev_mid) (void)hipEventDestroy(net->ev_mid);
     for (void* p : net->allocs) (void)hipFree(p);
     delete net;
 }
@@ -1042,6 +1053,7 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     return AEFFT_OK;
 }
 
+static int mark_step_point(aefft_net* n);
 // lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
 // discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
 static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool lazy)
@@ -1051,7 +1063,23 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     const int B = n->B, L = n->L;
     for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
-    RET_IF(do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
+    const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !getenv("AEFFT_NOPREFETCH");
+    if (prefetch) {
+        // The caller guarantees the frames are complete: their R2C goes to a side stream and may overlap the tail of the previous
+        // step.  It writes the OTHER input-spectra buffer (the current one is still read by that tail), which was last read two
+        // steps ago: wait for that step's end only.
+        std::swap(n->pr[0].X, n->X0alt);
+        if (n->ev_end_valid[n->step_no & 1]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_end[n->step_no & 1], 0));
+        // not earlier than the previous step's weight update: ahead of that point the step is bandwidth-bound itself (its own
+        // inverse FFT runs there) and an early R2C only slows it; behind it the kernels are latency-bound and leave HBM idle
+        if (n->ev_mid_valid && !getenv("AEFFT_PREFETCH_EARLY")) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_mid, 0));
+        ctx->cur = ctx->aux[1];
+        const int rc = do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID2);
+        ctx->cur = ctx->stream;
+        RET_IF(rc);
+        HIPCHK(ctx, hipEventRecord(n->ev_r2c, ctx->aux[1]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, n->ev_r2c, 0));
+    } else RET_IF(do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
     for (int l = 0; l < L; ++l) {
         Pair& q = n->pr[l];
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
@@ -1151,7 +1179,11 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     return AEFFT_OK;
 }
 
-extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* recon_d) { return net_forward(n, frames_d, recon_d, false); }
+extern "C" int aefft_net_forward(aefft_net* n, const float* frames_d, float* recon_d)
+{
+    RET_IF(net_forward(n, frames_d, recon_d, false));
+    return mark_step_point(n);
+}
 
 extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* ch, int* nx, int* ny)
 {
@@ -1189,7 +1221,8 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
         HIPCHK(ctx, hipMemcpyAsync(out_d, n->last_frames, sizeof(float) * B * c * x * y, hipMemcpyDeviceToDevice, ctx->stream));
         return AEFFT_OK;
     }
-    return do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y));
+    RET_IF(do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y)));
+    return mark_step_point(n);
 }
 
 // expand a decoder output that the training-step forward kept on its support only
@@ -1265,7 +1298,8 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
         HIPCHK(ctx, hipMemcpyAsync(mse_h, n->mse_dev, sizeof(float) * (n_iter + 1), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return AEFFT_OK;
+    q.G_valid = false;                                  // the burst changed this pair's weights (and used S)
+    return mark_step_point(n);
 }
 
 // Independent per-pair work is spread over side streams: fork() makes every side stream wait for
@@ -1479,6 +1513,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             hipError_t e = launch_update_group(ug, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
         }
+        if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
         hipError_t e;
         {
             Bracket br(ctx, KID_KSPEC, kbytes);
@@ -1585,10 +1620,35 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     return AEFFT_OK;
 }
 
+// input prefetch bookkeeping: everything of step k that reads this step's input-spectra buffer has been enqueued
+static int mark_step_point(aefft_net* n)
+{
+    if (!n->input_ready || !n->ev_end[0]) return AEFFT_OK;
+    HIPCHK(n->ctx, hipEventRecord(n->ev_end[n->step_no & 1], n->ctx->stream));
+    n->ev_end_valid[n->step_no & 1] = true;
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_set_input_ready(aefft_net* n, int enable)
+{
+    if (!n) return AEFFT_EINVAL;
+    aefft_ctx* ctx = n->ctx;
+    if (enable && !n->X0alt) {
+        const Pair& q = n->pr[0];
+        RET_IF(net_alloc_t(n, &n->X0alt, (size_t)n->B * q.dD * q.P));
+        for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipEventCreateWithFlags(&n->ev_end[i], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&n->ev_r2c, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&n->ev_mid, hipEventDisableTiming));
+    }
+    n->input_ready = enable != 0;
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* recon_d)
 {
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
+    ++n->step_no;
     RET_IF(net_forward(n, frames_d, recon_d, true));
     const bool side = use_side_streams(n);
     if (!side) {
@@ -1599,7 +1659,7 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
             n->recon_pending = false;
         }
         n->have_grad = true;
-        return AEFFT_OK;
+        return mark_step_point(n);
     }
     RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;
@@ -1610,7 +1670,7 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; n->recon_pending = false; }
     RET_IF(rc);
     n->have_grad = true;
-    return AEFFT_OK;
+    return mark_step_point(n);
 }
 
 extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloats)
@@ -1631,7 +1691,7 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     if (!side) {
         RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
         n->have_grad = false;
-        return AEFFT_OK;
+        return mark_step_point(n);
     }
     RET_IF(fork_streams(ctx));
     int rc = AEFFT_OK;
@@ -1643,5 +1703,5 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     RET_IF(rc);
     if (mse_d) HIPCHK(ctx, hipMemcpyAsync(mse_d, n->mse_post, sizeof(float) * n->L, hipMemcpyDeviceToDevice, ctx->stream));
     n->have_grad = false;
-    return AEFFT_OK;
+    return mark_step_point(n);
 }

@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="no side streams (for per-kernel traces)")
     ap.add_argument("--torch-stream", action="store_true", help="enqueue on torch's current (legacy default) stream instead of a private stream")
@@ -145,6 +146,8 @@ def main():
     torch.cuda.synchronize()                                              # inputs resident before anything is timed
     mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
     dp = importlib.import_module("autoencoder-fft_amd.dp")
+    if a.prefetch:
+        net.set_input_ready(True)                                         # input R2C on a side stream (measured neutral on MI355X: the step is throughput-bound)
     dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
     del0 = 0.2                                                            # autoencoder.cpp:87
 
@@ -182,7 +185,7 @@ def main():
         ctx.set_concurrency(False); ctx.prof_enable(True); ctx.prof_reset()
         for _ in range(3):
             net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
-        prof = ctx.prof_read(); ctx.prof_enable(False); ctx.set_concurrency(True)
+        prof = ctx.prof_read(); ctx.prof_enable(False)
         tot = sum(v["ms"] for v in prof.values())
         name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         per_launch_bytes = dom["bytes"] / dom["launches"]

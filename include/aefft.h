@@ -171,6 +171,12 @@ int aefft_net_train_pair(aefft_net* net, int l, int n_iter, float del0, int maxd
  *               pair, post-update MSE.  mse_d (nullable): [L] floats on the device.
  * Momentum persists across steps (reset with aefft_net_reset_momentum). */
 int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
+/* Opt-in input prefetch for pipelined training loops.  enable = 1 asserts that the frames handed to
+ * aefft_net_step_grad are COMPLETE in device memory when the call is made (not merely ordered on the
+ * context stream, e.g. a loader that synchronises its own copy stream): their R2C then runs on an
+ * internal side stream and may overlap the tail of the previous step still queued on the context
+ * stream (the input spectra are double-buffered).  Default 0: everything is ordered on the context stream. */
+int aefft_net_set_input_ready(aefft_net* net, int enable);
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 int aefft_net_step_apply(aefft_net* net, float del0, int maxdiff, int sym, float grad_scale, float* mse_d);
 int aefft_net_reset_momentum(aefft_net* net);

@@ -292,6 +292,36 @@ def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, monkeypatc
     net.close(); fresh.close()
 
 
+def test_input_prefetch_gives_identical_training(ctx):
+    """aefft_net_set_input_ready: the input R2C on a side stream with double-buffered input spectra only reorders work;
+    five steps with fresh frames each must leave exactly the weights of the stream-ordered run."""
+    rng = np.random.default_rng(321)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6], 5, 2, 4
+    ws = []
+    dD = D
+    for dM in maps:
+        _, cw, fw, bw, pw = _pair(rng, dD, dM, 8, Nk, 1)
+        ws.append((cw, bw, fw, pw)); dD = dM
+    frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(5)]
+    out = []
+    for ready in (False, True):
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        net.set_input_ready(ready)
+        recon, mse = ctx.empty(B, D, N, N), ctx.empty(len(maps))
+        for x in frames:
+            net.step_grad(x, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+        ctx.sync()
+        out.append(([net.get_pair(l) for l in range(len(maps))], host(recon).copy(), host(mse).copy()))
+        net.close()
+    for wa, wb in zip(out[0][0], out[1][0]):
+        for a, b in zip(wa, wb):
+            assert np.array_equal(a, b)
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-5)
+
+
 def test_spectra_store_load_roundtrip(ctx):
     """net_cfreq semantics: store_cfreq / load_cfreq (fft_backproplib.cu:1117-1141)."""
     rng = np.random.default_rng(3)
