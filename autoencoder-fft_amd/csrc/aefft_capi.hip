@@ -943,6 +943,15 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset weights", e); }
     if (!ctx->aux[0]) {
         for (int i = 0; i < aefft_ctx::NAUX; ++i) {
+            // AEFFT_CUMASK=<stride>[,<offset>]: side streams restricted to every <stride>-th CU (experiment: keep the bandwidth-bound
+            // side kernels from flooding the CUs the latency-bound main-stream kernels need)
+            const char* cm = getenv("AEFFT_CUMASK");
+            int stride = 0, offs = 0;
+            if (cm && sscanf(cm, "%d,%d", &stride, &offs) >= 1 && stride > 1) {
+                uint32_t mask[8] = {0};
+                for (int cu = 0; cu < 256; ++cu) if (cu % stride == (offs + i) % stride) mask[cu / 32] |= 1u << (cu % 32);
+                HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->aux[i], 8, mask));
+            } else
             HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
         }

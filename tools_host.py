@@ -14,6 +14,7 @@ for l, dM in enumerate(maps):
     dD = dM
 frames = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
 recon = ctx.empty(B, D, N, N); mse = ctx.empty(len(maps))
+if os.environ.get("NORECON"): recon = None
 net.set_input_ready(os.environ.get("READY", "1") == "1")
 for _ in range(10):
     net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
