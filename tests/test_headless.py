@@ -1,0 +1,102 @@
+"""End-to-end run of the headless driver (examples/headless.cpp): the reference application's main-loop orchestration over
+the vector API of libaefft.so, driven by a key script, against a replay of the same session with the oracle,
+including the reference's weight-file format through the `l` / `s` keys (8f-2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import np_ref as R  # noqa: E402
+
+DRIVER = os.path.join(ROOT, "autoencoder-fft_amd", "aefft_headless")
+
+
+def _weights_path(d, L, io, dD, dM, Lk, Ll, S):
+    return os.path.join(d, "weights", f"C_weights_{L}_{'in' if io == 0 else 'out'}_D={dD}_M={dM}_Lk={Lk}_Ll={Ll}_S={S}.conv")
+
+
+def _del_after(keys):
+    """the '5' key arithmetic of autoencoder.cpp:259-267 in float32"""
+    dl, dd = np.float32(0.2), np.float32(0.1)
+    for k in keys:
+        if k != '5':
+            continue
+        dl = np.float32(dl - dd)
+        if 0.1 < dl <= 1: dd = np.float32(0.1)
+        if 0.01 < dl <= 0.11: dd = np.float32(0.01)
+        if 0.001 < dl <= 0.011: dd = np.float32(0.001)
+        if 0.0001 < dl <= 0.0011: dd = np.float32(0.0001)
+        if dl < 0: dl = np.float32(0)
+    return float(dl)
+
+
+@pytest.mark.gpu
+def test_scripted_session_matches_oracle_replay(tmp_path):
+    if not os.path.exists(DRIVER):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "autoencoder-fft_amd", "csrc"), "headless"])
+    rng = np.random.default_rng(2024)
+    N, D, M, Lk, S, Nk = 32, 3, 4, 1, 2, 5
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "weights"))
+    with open(os.path.join(d, "New_Layer_Param.txt"), "w") as fh:
+        fh.write(f"M {M}\nLk {Lk}\nLl {Lk}\nS {S}\nrmax 3\n")
+    # key script, one key per frame: load weights, fft_l on, learning rate 0.2 -> smooth regime, train pair 0, add a pair,
+    # save it (so the replay knows its rand()-initialised weights), train it
+    script = "lg" + "5" * 11 + "1." + "ns1." + "."
+    F = len(script)
+    del0 = _del_after(script[:script.index('1')])
+    assert 0.005 < del0 < 0.02
+    video = np.floor(rng.uniform(0, 256, (F, D, N, N))).astype(np.float32)
+    video.tofile(os.path.join(d, "video.f32"))
+    c0 = rng.uniform(-1, 1, (M, D, Nk, Nk)).astype(np.float32); b0 = rng.uniform(-1, 1, M).astype(np.float32)
+    f0 = rng.uniform(-1, 1, (D, M, Nk, Nk)).astype(np.float32); p0 = rng.uniform(-1, 1, D).astype(np.float32)
+    np.concatenate([c0.ravel(), b0]).tofile(_weights_path(d, 0, 0, D, M, Lk, Lk, S))
+    np.concatenate([f0.ravel(), p0]).tofile(_weights_path(d, 0, 1, M, D, Lk, Lk, -S))
+    out = subprocess.run([DRIVER, "--size", str(N), "--frames", str(F), "--script", script, "--video", "video.f32", "--seed", "5",
+                          "--dump", "final.f32"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Added new layer L 2" in out.stdout and "pairs=2" in out.stdout and "sel=0" in out.stdout
+
+    # ---- replay with the oracle ----
+    f64 = np.float64
+    t_train0 = script.index('1') + 1                      # the frame after the key: forward, then the burst (sel was set)
+    lay, cf, _ = R.autoenc_fft(video[t_train0].astype(f64), [c0.astype(f64), f0.astype(f64)], [b0.astype(f64), p0.astype(f64)], [S, -S])
+    r0 = R.backprop_fft(lay[1], lay[1], lay[3], cf[0], c0.astype(f64), cf[1], f0.astype(f64), b0.astype(f64), p0.astype(f64), del0, n_iter=100)
+    # the new pair's initial weights, as saved by the `s` key (reference file format): pair index 1, D=M (hidden maps of pair 0)
+    w_in = np.fromfile(_weights_path(d, 1, 0, M, M, Lk, Lk, S), np.float32)
+    w_out = np.fromfile(_weights_path(d, 1, 1, M, M, Lk, Lk, -S), np.float32)
+    c1 = w_in[:M * M * Nk * Nk].reshape(M, M, Nk, Nk); b1 = w_in[M * M * Nk * Nk:]
+    f1 = w_out[:M * M * Nk * Nk].reshape(M, M, Nk, Nk); p1 = w_out[M * M * Nk * Nk:]
+    assert np.abs(c1).max() <= 3.0 and np.abs(c1).max() > 1.0          # Init_conv with rmax = 3
+    t_train1 = t_train0 + 1 + script[t_train0:].index('1')
+    net_c = [r0["c"], c1.astype(f64), f1.astype(f64), r0["f"]]
+    net_b = [r0["b"], b1.astype(f64), p1.astype(f64), r0["p"]]
+    lay, cf, _ = R.autoenc_fft(video[t_train1].astype(f64), net_c, net_b, [S, S, -S, -S])
+    # pair 1: in = layers[3], out = layers[size-2-2] = layers[5]
+    r1 = R.backprop_fft(lay[3], lay[3], lay[5], cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del0, n_iter=100)
+    # the rmax = 3 kernels of the new pair put its burst in the clipped (sign-like) regime where trajectories are sensitive to
+    # rounding (chaotic horizon): the yardstick there is the oracle's own float32 replay
+    f32 = np.float32
+    r1_32 = R.backprop_fft(lay[3].astype(f32), lay[3].astype(f32), lay[5].astype(f32), cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del0,
+                           n_iter=100, dtype=f32)
+    slack1 = 4.0 * max(np.abs(r1_32[k] - r1[k]).max() for k in ("c", "f", "b", "p"))
+    lay_end, _, _ = R.autoenc_fft(video[F - 1].astype(f64), [r0["c"], r1["c"], r1["f"], r0["f"]], [r0["b"], r1["b"], r1["p"], r0["p"]], [S, S, -S, -S])
+
+    final = np.fromfile(os.path.join(d, "final.f32"), np.float32)
+    expect = [(r0["c"], r0["b"]), (r1["c"], r1["b"]), (r1["f"], r1["p"]), (r0["f"], r0["p"])]
+    start = [(c0, b0), (c1, b1), (f1, p1), (f0, p0)]
+    off = 0
+    for n, ((w, bias), (w_start, _)) in enumerate(zip(expect, start)):
+        got_w = final[off:off + w.size].reshape(w.shape); off += w.size
+        got_b = final[off:off + bias.size]; off += bias.size
+        dw = np.abs(w - w_start).max()
+        assert dw > 1e-3
+        tol = 2e-5 + 1e-3 * dw + (slack1 if n in (1, 2) else 0.0)
+        assert np.abs(got_w - w).max() < tol, (n, np.abs(got_w - w).max(), tol, dw)
+        assert np.abs(got_b - bias).max() < tol, (n, np.abs(got_b - bias).max(), tol)
+    got_out = final[off:].reshape(D, N, N)
+    assert np.abs(got_out - lay_end[-1]).max() < 1e-3 * np.abs(lay_end[-1]).max() + 50 * slack1 * np.abs(lay_end[-1]).max()
