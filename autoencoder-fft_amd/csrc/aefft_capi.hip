@@ -785,7 +785,8 @@ struct Pair {
     float2 *C, *F;
     bool spectra_valid;
     bool H_stale = false;    // the last (lazy) forward produced only the pooled part of H: recompute before reading H
-    bool G_valid = false;    // S holds G = F.C/(dM dD) of the CURRENT weights and beta its DC bias (left there by aefft_net_step_apply)
+    float2* G = nullptr;     // [dD][dD][P] collapsed pair operator F.C/(dM dD) (post-update MSE; innermost pair's forward)
+    bool G_valid = false;    // G and beta (its DC bias) belong to the CURRENT weights (left by aefft_net_step_apply)
     float* beta = nullptr;   // [dD]
     float* Q = nullptr;      // [dD][dD][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip)
     float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
@@ -822,6 +823,7 @@ struct aefft_net {
     bool ev_mid_valid = false;
     bool ev_end_valid[2] = {false, false};
     unsigned long step_no = 0;
+    bool xx_done = false;         // the forward already launched S = -sum_b X X^H (grouped with the innermost decoder conv)
     bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
     bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
     // shared scratch sized for the largest pair
@@ -888,7 +890,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         else if ((rc = net_alloc_t(n, &q.X, BDP))) break;
         if ((rc = net_alloc_t(n, &q.H, BMP)) || (rc = net_alloc_t(n, &q.O, BDP))) break;
         q.Oc = nullptr;
-        if ((rc = net_alloc_t(n, &q.S, (size_t)q.dD * q.dD * q.P)) || (rc = net_alloc_t(n, &q.dc, 2 * W))) break;
+        if ((rc = net_alloc_t(n, &q.S, (size_t)q.dD * q.dD * q.P)) || (rc = net_alloc_t(n, &q.G, (size_t)q.dD * q.dD * q.P)) || (rc = net_alloc_t(n, &q.dc, 2 * W))) break;
         q.df = q.dc + W;
         q.part = nullptr;
         if (pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny)) { if ((rc = net_alloc_t(n, &q.part, kgrad_partial_floats(2L * q.dM * q.dD, q.Nx, q.Ny, q.Nk, q.Nl)))) break; }
@@ -1126,11 +1128,21 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         if (l == L - 1) {
             if (q.H_stale) {                       // (set above: G route)
                 Contract k{};
-                k.A = q.S; k.a_r = (long)q.dD * q.P; k.a_k = q.P;
+                k.A = q.G; k.a_r = (long)q.dD * q.P; k.a_k = q.P;
                 k.B = q.X; k.b_k = q.P; k.b_c = (long)q.dD * q.P;
                 k.Out = q.O; k.o_r = q.P; k.o_c = (long)q.dD * q.P;
                 k.R = q.dD; k.C = B; k.K = q.dD; k.P = q.P;
                 k.bias = q.beta; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
+                // the batch-first gradient term S = -sum_b X X^H needs only the encoder outputs: it shares this launch
+                // (the decoder chain that follows is a sequence of small dependent launches)
+                n->xx_done = false;
+                if (compact && n->pr[0].P != n->Pc && L + 1 <= 8 && !getenv("AEFFT_NOGROUP")) {
+                    Contract qs[8];
+                    qs[0] = k;
+                    for (int l2 = 0; l2 < L; ++l2) { Pair& q2 = n->pr[l2]; qs[1 + l2] = mk_XXneg(q2.X, q2.S, B, q2.dD, q2.P); }
+                    RET_IF(do_contract_group(ctx, qs, L + 1, L + 1, 0));
+                    n->xx_done = true;
+                } else
                 RET_IF(do_contract(ctx, k));
             } else RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny));
             continue;
@@ -1355,7 +1367,7 @@ static int grads_grouped(aefft_net* n)
     aefft_ctx* ctx = n->ctx;
     Contract qs[8];
     bool comp = false;
-    for (int l = 0; l < n->L; ++l) { comp = comp || n->pr[l].O_stale; n->pr[l].G_valid = false; }      // S is about to overwrite G
+    for (int l = 0; l < n->L; ++l) comp = comp || n->pr[l].O_stale;
     for (int l0 = 0; l0 < n->L; l0 += 4) {
         const int m = std::min(4, n->L - l0);
         if (!comp) {
@@ -1363,8 +1375,10 @@ static int grads_grouped(aefft_net* n)
             RET_IF(do_contract_group(ctx, qs, m, m, 1));
             continue;
         }
-        for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_XXneg(q.X, q.S, n->B, q.dD, q.P); }
-        RET_IF(do_contract_group(ctx, qs, m, m, 1));
+        if (!n->xx_done) {
+            for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_XXneg(q.X, q.S, n->B, q.dD, q.P); }
+            RET_IF(do_contract_group(ctx, qs, m, m, 1));
+        }
         for (int i = 0; i < m; ++i) {
             Pair& q = n->pr[l0 + i];
             qs[i] = q.O_stale ? mk_OX(q.Oc, q.X, q.S, n->B, q.dD, q.P, n->Pc, q.Nx, q.Ny, n->NxC, n->NyC)
@@ -1372,6 +1386,7 @@ static int grads_grouped(aefft_net* n)
         }
         RET_IF(do_contract_group(ctx, qs, m, m, 1));
     }
+    n->xx_done = false;
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
     const char* nogroup = getenv("AEFFT_NOGROUP");
     bool same = n->L > 1 && n->L <= 8 && !nogroup;
@@ -1477,8 +1492,8 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_i
     aefft_ctx* ctx = n->ctx;
     const char* nofuse = getenv("AEFFT_NOFUSEMSE");
     if (!nofuse && q.dD >= 2 && n->B >= 2) {
-        RET_IF(do_contract(ctx, mk_G(q.F, q.C, q.S, q.dM, q.dD, q.P)));
-        const Contract m = mk_gmse(q.S, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
+        RET_IF(do_contract(ctx, mk_G(q.F, q.C, q.G, q.dM, q.dD, q.P)));
+        const Contract m = mk_gmse(q.G, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
         hipError_t e;
         {
             Bracket br(ctx, KID_CONTRACT, ((double)m.R * m.K + 2.0 * m.K * m.C) * m.P * 8.0);
@@ -1496,6 +1511,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_i
 static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gscale, float* mse_d)
 {
     aefft_ctx* ctx = n->ctx;
+    for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
     const char* nogroup1 = getenv("AEFFT_NOGROUP");
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
@@ -1553,8 +1569,8 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         for (int l = 0; l < n->L; ++l) {
             Pair& q = n->pr[l];
             if (!nofuse && !nogroup && q.dD >= 2 && n->B >= 2 && m < 8) {
-                gq[m] = mk_G(q.F, q.C, q.S, q.dM, q.dD, q.P);
-                mq[m] = mk_gmse(q.S, q.X, q.F, q.b, q.p, n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, n->B, q.dM, q.dD, q.Nx, q.Ny);
+                gq[m] = mk_G(q.F, q.C, q.G, q.dM, q.dD, q.P);
+                mq[m] = mk_gmse(q.G, q.X, q.F, q.b, q.p, n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, n->B, q.dM, q.dD, q.Nx, q.Ny);
                 ++m;
             } else rest.push_back(l);
         }
@@ -1576,7 +1592,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
                 for (int l = 0; l < n->L; ++l) {
                     Pair& q = n->pr[l];
                     gg.q[l] = GspProb{q.c, q.f, q.Q, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};     // Q is dead after the weight gradients: reused for gsp
-                    pg.q[l] = PrunedProb{q.Q, q.S, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
+                    pg.q[l] = PrunedProb{q.Q, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
                     gbytes += (2.0 * q.dM * q.dD * q.Nk * q.Nl + (double)q.dD * q.dD * T * T) * 4.0;
                     kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
                 }

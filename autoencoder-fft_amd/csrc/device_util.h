@@ -79,6 +79,7 @@ template <> struct BufLoad<2> {
 
 
 // DC-bin terms of gradient_k_io (see bias_grad_kernel, spectral_kernels.hip)
+static inline size_t bias_grad_lds(int B, int dD) { return sizeof(float2) * ((size_t)dD + (size_t)B * dD); }
 __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
                                                         const float2* __restrict__ F, const float* __restrict__ b,
                                                         float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
@@ -86,15 +87,20 @@ __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, con
 {
     // written for 256 threads; in a larger workgroup (the fused kgrad launch) the extra threads only take part in the barriers
     const bool wk = threadIdx.x < 256;
+    // es[d] = sum over frames, in FRAME ORDER (deterministic: 100-iteration bursts amplify any run-to-run rounding difference).
+    // LDS: es[dD] complex, then the B*dD per-frame DC differences (callers size the dynamic LDS with bias_grad_lds()).
     float* esf = reinterpret_cast<float*>(es);
-    if (wk) for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = 0.f;
-    __syncthreads();
+    float2* val = es + dD;
     // (frame, channel) pairs spread over the threads so the B*dD DC-bin loads are all in flight at once
     if (wk) for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
-        const int d = idx % dD;
         const float2 o = O[(long)idx * PO], t = T[(long)idx * P];
-        atomicAdd(&esf[2 * d], o.x - t.x);
-        atomicAdd(&esf[2 * d + 1], o.y - t.y);
+        val[idx] = make_float2(o.x - t.x, o.y - t.y);
+    }
+    __syncthreads();
+    if (wk) for (int d = threadIdx.x; d < dD; d += 256) {
+        float sx = 0.f, sy = 0.f;
+        for (int b2 = 0; b2 < B; ++b2) { const float2 v = val[b2 * dD + d]; sx += v.x; sy += v.y; }
+        esf[2 * d] = sx; esf[2 * d + 1] = sy;
     }
     __syncthreads();
     if (!wk) return;

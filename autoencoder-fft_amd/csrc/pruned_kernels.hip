@@ -442,15 +442,13 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
     BiasGradGroup bg{};
     int extra = 0;
     if (bgp) {
-        int dDmax = 0;
         for (int i = 0; i < bgp->n; ++i) {
             const BiasGradArgs& a = bgp->a[i];
             bgp->fix[i] = (a.dM * a.dD + 255) / 256;
             bgp->start[i] = extra; extra += bgp->fix[i] + (a.dM + 3) / 4;
-            dDmax = std::max(dDmax, a.dD);
+            lds = std::max(lds, bias_grad_lds(a.B, a.dD));
         }
         bgp->start[bgp->n] = extra;
-        lds = std::max(lds, sizeof(float2) * (size_t)dDmax);
         bg = *bgp;
     }
     kgrad_group_kernel<NK, NL, NT><<<dim3(total + extra), NT, lds, st>>>(g, tw, bg);

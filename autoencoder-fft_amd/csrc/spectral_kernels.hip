@@ -918,7 +918,7 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
 {
     __shared__ float ws[MSE_SLOTS / 64];
     __shared__ float bacc[256];
-    if (ba.beta) {
+    if (blockIdx.x == 1) {                               // second workgroup (only launched when beta is wanted): runs beside the sums
         for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) bacc[d] = 0.f;
         __syncthreads();
         for (int i = threadIdx.x; i < ba.dD * ba.dM; i += MSE_SLOTS) {
@@ -927,6 +927,7 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
         }
         __syncthreads();
         for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) ba.beta[d] = ba.p[d] + bacc[d] / (float)ba.dD;
+        return;
     }
     for (int l = 0; l < L; ++l) {
         float* s = slots + ((long)l * MSE_SLOTS + threadIdx.x) * MSE_SLOT_STRIDE;
@@ -950,7 +951,7 @@ hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipSt
 {
     BetaArgs a{};
     if (ba && ba->dD <= 256) a = *ba;
-    mse_finish_kernel<<<1, MSE_SLOTS, 0, st>>>(slots, out, copy, L, a);
+    mse_finish_kernel<<<a.beta ? 2 : 1, MSE_SLOTS, 0, st>>>(slots, out, copy, L, a);
     return hipGetLastError();
 }
 
@@ -977,15 +978,16 @@ __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGrou
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st)
 {
     if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
-    int total = 0, dDmax = 0;
+    int total = 0; size_t lds = 0;
     for (int i = 0; i < g.n; ++i) {
         const BiasGradArgs& a = g.a[i];
         g.fix[i] = (a.dM * a.dD + 255) / 256;
         g.start[i] = total; total += g.fix[i] + (a.dM + 3) / 4;
-        dDmax = std::max(dDmax, a.dD);
+        lds = std::max(lds, bias_grad_lds(a.B, a.dD));
     }
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
     g.start[g.n] = total;
-    bias_grad_group_kernel<<<dim3(total), 256, sizeof(float2) * dDmax, st>>>(g);
+    bias_grad_group_kernel<<<dim3(total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 
@@ -993,7 +995,8 @@ hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, c
                             int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st)
 {
     const int fix_blocks = (dM * dD + 255) / 256;
-    bias_grad_kernel<<<dim3(fix_blocks + (dM + 3) / 4), 256, sizeof(float2) * dD, st>>>(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks);
+    if (bias_grad_lds(B, dD) > 64 * 1024) return hipErrorInvalidValue;
+    bias_grad_kernel<<<dim3(fix_blocks + (dM + 3) / 4), 256, bias_grad_lds(B, dD), st>>>(O, T, F, b, df, db, dp, B, dM, dD, P, norm, Norm, fix_blocks);
     return hipGetLastError();
 }
 

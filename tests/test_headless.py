@@ -43,7 +43,7 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "weights"))
     with open(os.path.join(d, "New_Layer_Param.txt"), "w") as fh:
-        fh.write(f"M {M}\nLk {Lk}\nLl {Lk}\nS {S}\nrmax 3\n")
+        fh.write(f"M {M}\nLk {Lk}\nLl {Lk}\nS {S}\nrmax 1\n")      # rmax 1: keeps the added pair's burst in the smooth regime
     # key script, one key per frame: load weights, fft_l on, learning rate 0.2 -> smooth regime, train pair 0, add a pair,
     # save it (so the replay knows its rand()-initialised weights), train it
     script = "lg" + "5" * 11 + "1." + "ns1." + "."
@@ -71,15 +71,15 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
     w_out = np.fromfile(_weights_path(d, 1, 1, M, M, Lk, Lk, -S), np.float32)
     c1 = w_in[:M * M * Nk * Nk].reshape(M, M, Nk, Nk); b1 = w_in[M * M * Nk * Nk:]
     f1 = w_out[:M * M * Nk * Nk].reshape(M, M, Nk, Nk); p1 = w_out[M * M * Nk * Nk:]
-    assert np.abs(c1).max() <= 3.0 and np.abs(c1).max() > 1.0          # Init_conv with rmax = 3
+    assert 0.5 < np.abs(c1).max() <= 1.0                               # Init_conv with rmax = 1
     t_train1 = t_train0 + 1 + script[t_train0:].index('1')
     net_c = [r0["c"], c1.astype(f64), f1.astype(f64), r0["f"]]
     net_b = [r0["b"], b1.astype(f64), p1.astype(f64), r0["p"]]
     lay, cf, _ = R.autoenc_fft(video[t_train1].astype(f64), net_c, net_b, [S, S, -S, -S])
     # pair 1: in = layers[3], out = layers[size-2-2] = layers[5]
     r1 = R.backprop_fft(lay[3], lay[3], lay[5], cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del0, n_iter=100)
-    # the rmax = 3 kernels of the new pair put its burst in the clipped (sign-like) regime where trajectories are sensitive to
-    # rounding (chaotic horizon): the yardstick there is the oracle's own float32 replay
+    # 100 clipped-momentum iterations amplify rounding differences (chaotic horizon): the yardstick for the
+    # second burst, which starts from the first one's result, is the oracle's own float32 replay
     f32 = np.float32
     r1_32 = R.backprop_fft(lay[3].astype(f32), lay[3].astype(f32), lay[5].astype(f32), cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del0,
                            n_iter=100, dtype=f32)
