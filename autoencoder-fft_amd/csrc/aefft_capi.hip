@@ -1711,6 +1711,7 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
     if (!n->have_grad) return fail(ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
+    for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change (the grouped path re-derives G and sets it again)
     const float del = 0.1f * del0;
     const bool side = use_side_streams(n) && !maxdiff;        // the multiobjective path shares context workspaces
     if (!side) {
