@@ -823,6 +823,7 @@ struct aefft_net {
     bool ev_mid_valid = false;
     bool ev_end_valid[2] = {false, false};
     unsigned long step_no = 0;
+    unsigned ox_done = 0;         // bit l: the forward already launched pair l's support term S += sum_b Oc X^H
     bool xx_done = false;         // the forward already launched S = -sum_b X X^H (grouped with the innermost decoder conv)
     bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
     bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
@@ -1072,6 +1073,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     if (!n || !frames_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_forward: bad argument");
     aefft_ctx* ctx = n->ctx;
     const int B = n->B, L = n->L;
+    n->xx_done = false; n->ox_done = 0;
     for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
     const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !getenv("AEFFT_NOPREFETCH");
@@ -1135,7 +1137,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
                 k.bias = q.beta; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
                 // the batch-first gradient term S = -sum_b X X^H needs only the encoder outputs: it shares this launch
                 // (the decoder chain that follows is a sequence of small dependent launches)
-                n->xx_done = false;
+                n->xx_done = false; n->ox_done = 0;
                 if (compact && n->pr[0].P != n->Pc && L + 1 <= 8 && !getenv("AEFFT_NOGROUP")) {
                     Contract qs[8];
                     qs[0] = k;
@@ -1160,6 +1162,16 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             k.preDivB = (float)q.dD;
             k.bias = q.p; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
             k.gdNx = q.Nx; k.gdNy = q.Ny; k.gdNxs = n->NxC; k.gdNys = n->NyC; k.gdMask = 1;
+            if (n->xx_done && !getenv("AEFFT_NOGROUP") && !getenv("AEFFT_NOMFMA")) {
+                // S = -sum_b X X^H is already out: the support term of the NEXT-inner pair (its decoder output is final) rides along
+                Pair& qi = n->pr[l + 1];
+                Contract qs[2] = {k, qi.O_stale ? mk_OX(qi.Oc, qi.X, qi.S, B, qi.dD, qi.P, n->Pc, qi.Nx, qi.Ny, n->NxC, n->NyC)
+                                                : mk_OX(qi.O, qi.X, qi.S, B, qi.dD, qi.P, qi.P, qi.Nx, qi.Ny, qi.Nx, qi.Ny)};
+                RET_IF(do_contract_group(ctx, qs, 2, 2, 0));
+                n->ox_done |= 1u << (l + 1);
+                q.O_stale = true;
+                continue;
+            }
             hipError_t e;
             {
                 Bracket br(ctx, KID_CONTRACT, ((double)k.R * k.K + (double)k.K * k.C + (double)k.R * k.C) * k.P * 8.0);
@@ -1379,14 +1391,17 @@ static int grads_grouped(aefft_net* n)
             for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_XXneg(q.X, q.S, n->B, q.dD, q.P); }
             RET_IF(do_contract_group(ctx, qs, m, m, 1));
         }
+        int mo = 0;
         for (int i = 0; i < m; ++i) {
             Pair& q = n->pr[l0 + i];
-            qs[i] = q.O_stale ? mk_OX(q.Oc, q.X, q.S, n->B, q.dD, q.P, n->Pc, q.Nx, q.Ny, n->NxC, n->NyC)
-                              : mk_OX(q.O, q.X, q.S, n->B, q.dD, q.P, q.P, q.Nx, q.Ny, q.Nx, q.Ny);
+            if (n->xx_done && (n->ox_done >> (l0 + i) & 1u)) continue;          // rode along with a decoder launch of the forward
+            qs[mo++] = q.O_stale ? mk_OX(q.Oc, q.X, q.S, n->B, q.dD, q.P, n->Pc, q.Nx, q.Ny, n->NxC, n->NyC)
+                                 : mk_OX(q.O, q.X, q.S, n->B, q.dD, q.P, q.P, q.Nx, q.Ny, q.Nx, q.Ny);
         }
-        RET_IF(do_contract_group(ctx, qs, m, m, 1));
+        if (mo == 1) RET_IF(do_contract(ctx, qs[0]));
+        else if (mo > 1) RET_IF(do_contract_group(ctx, qs, mo, mo, 1));
     }
-    n->xx_done = false;
+    n->xx_done = false; n->ox_done = 0;
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
     const char* nogroup = getenv("AEFFT_NOGROUP");
     bool same = n->L > 1 && n->L <= 8 && !nogroup;
