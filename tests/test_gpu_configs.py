@@ -124,3 +124,45 @@ def test_config5_full_size_runs(ctx):
         c2, b2, f2, p2 = net.get_pair(l)
         assert np.isfinite(c2).all() and np.array_equal(f2, np.transpose(c2, (1, 0, 2, 3)))
     net.close()
+
+
+LITERAL = ["AEFFT_NOLAZY", "AEFFT_NOCOMPACT", "AEFFT_NOQPATH", "AEFFT_NOFUSEMSE", "AEFFT_NOGROUP", "AEFFT_NOMFMA", "AEFFT_NOGFWD",
+           "AEFFT_NOOVERLAP", "AEFFT_NOFUSECROP"]
+
+
+@pytest.mark.gpu
+def test_optimised_step_equals_literal_sequence_over_three_steps(ctx, monkeypatch):
+    """Config-2 sized net (256x256, 3 pairs, pool 2), B = 4, three training steps on fresh frames: the default path (matrix
+    cores, pooled-grid encoder, support-only decoder, Q-path gradients, collapsed operator, grouped launches) against the
+    same library with every one of those switched off, i.e. the literal conv / S / dc,df / C2R / update / R2C / conv, conv /
+    MSE sequence on scalar-FMA kernels.  Guards the re-associations at a size the numpy oracle is too slow for."""
+    rng = np.random.default_rng(77)
+    D, N, maps, Nk, s, B = 3, 256, [8, 16, 32], 5, 2, 4
+    ws = _weights(rng, D, maps, Nk, 1.0)
+    frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(3)]
+    res = []
+    for literal in (True, False):
+        for k in LITERAL:
+            if literal:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        recon, mse = ctx.empty(B, D, N, N), ctx.empty(len(maps))
+        grads = []
+        for x in frames:
+            net.step_grad(x, recon)
+            grads.append(host(net.grad_buffer()).copy())
+            net.step_apply(0.02, 0, 0, 1.0, mse)
+        res.append((grads, [net.get_pair(l) for l in range(len(maps))], host(recon).copy(), host(mse).copy()))
+        net.close()
+    (g_lit, w_lit, r_lit, m_lit), (g_opt, w_opt, r_opt, m_opt) = res
+    assert np.abs(g_lit[0] - g_opt[0]).max() < 5e-5 * np.abs(g_lit[0]).max()          # step 1: identical weights on both sides
+    for l, (a, b) in enumerate(zip(w_lit, w_opt)):
+        for x, y, w0 in zip(a, b, ws[l]):
+            dw = np.abs(x - w0).max()
+            assert np.abs(x - y).max() < 1e-6 + 2e-3 * dw
+    assert np.abs(r_lit - r_opt).max() < 1e-3 * np.abs(r_lit).max()
+    assert np.allclose(m_lit, m_opt, rtol=2e-3)
