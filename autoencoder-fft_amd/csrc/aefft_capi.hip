@@ -747,6 +747,12 @@ extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const f
     a.in = in_d; a.out = out_d; a.hin = hin_d; a.f = f_d;
     a.gc = (float*)small; a.gf = a.gc + nk; a.gb = a.gf + nk; a.gp = a.gb + dM;
     a.ws = (float*)ws;
+    {
+        const size_t pf = spatial_partial_floats(B, dD, dM, Nx, Nk, Nl);
+        void* part = nullptr;
+        if (pf) RET_IF(ws_get(ctx, WS_PART, sizeof(float) * pf, &part));
+        a.part = (float*)part;
+    }
     a.B = B; a.dD = dD; a.dM = dM; a.Nx = Nx; a.Ny = Ny; a.Nk = Nk; a.Nl = Nl;
     spatial_geom(Nk, Nl, cpu_semantics, &a.ak, &a.al, &a.lo);
     a.Norm = (float)(dD * dM * Nk * Nl * Nx * Ny);            // backproplib.cu:303

@@ -142,11 +142,13 @@ struct SpatialGradArgs {
     const float *in, *out, *hin, *f;      // [dD][Nx][Ny], [dD][Nx][Ny], [dM][Nx][Ny], [dD][dM][Nk][Nl]
     float *gc, *gf, *gb, *gp;             // [dM][dD][Nk][Nl], [dD][dM][Nk][Nl], [dM], [dD]
     float *ws;                            // workspace: dM*Nx*Ny (back-conv) floats
+    float *part;                          // workspace: spatial_partial_floats() floats (tiled weight-gradient partial sums); null: naive kernels
     int B, dD, dM, Nx, Ny, Nk, Nl, ak, al;
     float Norm;
     int lo;                               // 0: GPU boundary test '>=0' (backproplib.cu:95), 1: CPU test '>0' (netlib.cpp:344)
     int tied;                             // backprop_gpu_cc: add the f-gradient into the c-gradient (backproplib.cu:466)
 };
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st);
+size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl);   // 0: shape not served by the tiled kernels
 
 }  // namespace aefft

@@ -16,6 +16,8 @@
 //                         with the reference's range tests on every shifted index (lo = 0: '>=0',
 //                         backproplib.cu:209,213; lo = 1: '>0', netlib.cpp:412,416).
 #include "internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace aefft {
 
@@ -48,11 +50,287 @@ __global__ __launch_bounds__(256) void conv_spatial_kernel(const float* __restri
     out[n] = h + b[m];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled forms for the kernel sizes the application uses (3x3, 5x5, 7x7).
+//
+// dconv_kernel<TM,NK>: direct convolution / back-convolution.  A workgroup owns a 16x16 output tile of TM output maps of
+// one frame; per input channel the (16+NK-1)^2 input tile is staged in LDS once (range tests, the out-in subtraction and
+// the /dM of Conv_gpu, backproplib.cu:134, applied while staging), then every thread runs NK*NK taps x TM maps out of
+// LDS with the weights in scalar registers (uniform indices -> s_load).  Summation order d, k, l as in the reference loops.
+// ------------------------------------------------------------------------------------------
+struct DConvArgs {
+    const float *in, *in2;      // input planes [B][Din][Nx][Ny]; in2 != null: the input is in - in2 (s0 = out - in, backproplib.cu:312)
+    const float* w;             // weight of (m, d, k, l) at w[m*w_m + d*w_d + k*Nl + l]
+    const float* bias;          // [M] or null
+    float* out;                 // [B][M][Nx][Ny]
+    int Din, M, Nx, Ny, w_m, w_d;
+    int ik0, il0;               // tap k sits at offset ik0 + k (backproplib.cu:85: -2*ak-1+k)
+    int sgn;                    // -1: input index = i - offset (conv_parallel); +1: i + offset (back-convolution through f)
+    int lo_in, hi_lo;           // valid input indices [lo_in, N); outputs with i < hi_lo or j < hi_lo are 0 (back-conv with lo = 1)
+    float div;                  // input divided by this while staging (1: none)
+};
+
+template <int TM, int NK>
+__global__ __launch_bounds__(256) void dconv_kernel(const DConvArgs a)
+{
+    constexpr int TW = 16 + NK - 1, DC = 8;              // DC input channels staged per barrier pair
+    __shared__ float tile[DC][TW * TW];
+    const int tiles_y = (a.Ny + 15) / 16;
+    const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
+    const int m0 = blockIdx.y * TM;
+    const long bb = blockIdx.z;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int i = ti * 16 + ty, j = tj * 16 + tx;
+    // first input row / column the tile needs
+    const int r0 = a.sgn < 0 ? ti * 16 - a.ik0 - (NK - 1) : ti * 16 + a.ik0;
+    const int c0 = a.sgn < 0 ? tj * 16 - a.il0 - (NK - 1) : tj * 16 + a.il0;
+    const long plane = (long)a.Nx * a.Ny;
+    float acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) acc[t] = 0.f;
+    for (int d0 = 0; d0 < a.Din; d0 += DC) {
+        const int nd = min(DC, a.Din - d0);
+        __syncthreads();
+        // staging in branch-free batches of 8 loads per thread (a rolled loop is one memory round trip per element under hipcc)
+        for (int t0 = 0; t0 < nd * TW * TW; t0 += 256 * 8) {
+            float v[8], v2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256 + threadIdx.x;
+                const int dl = min(t / (TW * TW), nd - 1), q = t % (TW * TW);
+                const int r = r0 + q / TW, cc = c0 + q % TW;
+                const bool ok = t < nd * TW * TW && r >= a.lo_in && r < a.Nx && cc >= a.lo_in && cc < a.Ny;
+                const long idx = ok ? (bb * a.Din + d0 + dl) * plane + (long)r * a.Ny + cc : 0;
+                v[u] = a.in[idx];
+                v2[u] = a.in2 ? a.in2[idx] : 0.f;
+                if (!ok) { v[u] = 0.f; v2[u] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256 + threadIdx.x;
+                if (t >= nd * TW * TW) break;
+                float x = v[u] - v2[u];
+                if (a.div != 1.f) x = x / a.div;
+                tile[t / (TW * TW)][t % (TW * TW)] = x;
+            }
+        }
+        __syncthreads();
+        for (int dl = 0; dl < nd; ++dl) {
+            const float* wd = a.w + (long)(d0 + dl) * a.w_d;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int l = 0; l < NK; ++l) {
+                    const float x = tile[dl][(a.sgn < 0 ? ty + (NK - 1 - k) : ty + k) * TW + (a.sgn < 0 ? tx + (NK - 1 - l) : tx + l)];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        const int m = m0 + t < a.M ? m0 + t : a.M - 1;        // uniform: the weight comes through a scalar load
+                        acc[t] = fmaf(wd[(long)m * a.w_m + k * NK + l], x, acc[t]);
+                    }
+                }
+        }
+    }
+    if (i >= a.Nx || j >= a.Ny) return;
+    const bool zero = i < a.hi_lo || j < a.hi_lo;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int m = m0 + t;
+        if (m >= a.M) break;
+        a.out[(bb * a.M + m) * plane + (long)i * a.Ny + j] = zero ? 0.f : acc[t] + (a.bias ? a.bias[m] : 0.f);
+    }
+}
+
+template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStream_t st)
+{
+    const int tiles = ((a.Nx + 15) / 16) * ((a.Ny + 15) / 16);
+    if (a.M >= 12) dconv_kernel<16, NK><<<dim3(tiles, (a.M + 15) / 16, B), 256, 0, st>>>(a);
+    else if (a.M >= 6) dconv_kernel<8, NK><<<dim3(tiles, (a.M + 7) / 8, B), 256, 0, st>>>(a);
+    else dconv_kernel<4, NK><<<dim3(tiles, (a.M + 3) / 4, B), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+static bool dconv_ok(int Nk, int Nl, int B) { return Nk == Nl && (Nk == 3 || Nk == 5 || Nk == 7) && B <= 65535; }
+static hipError_t launch_dconv(const DConvArgs& a, int Nk, int B, hipStream_t st)
+{
+    if (Nk == 3) return run_dconv<3>(a, B, st);
+    if (Nk == 5) return run_dconv<5>(a, B, st);
+    return run_dconv<7>(a, B, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// wcorr_kernel<TA,TB,NK>: weight-gradient correlations
+//     out[a][b][k][l] = sum_{frames, pixels} A[a][i][j] * Bp[b][i - ik][j - il]        (shifted index inside [lo, N))
+// (dC: A = back-convolved error g, Bp = in; dF: A = out - in, Bp = hin; backproplib.cu:200-230,340-388 summed over the
+// image instead of one launch + reduce per weight element).  A workgroup owns a 16-row band of one frame and a (TA x TB)
+// tile of plane pairs: per 16x16 sub-tile the TB shifted planes are staged in LDS, every thread keeps TA*TB*NK*NK partial
+// sums for its pixel column, reduced once at the end (wave shuffles, LDS across waves) into part[workgroup][...].  The
+// plane sums of A (the bias gradients, :231,389) fall out of the same pass.  wsum_kernel adds the partials in a fixed order.
+// ------------------------------------------------------------------------------------------
+struct WCorrArgs {
+    const float *A, *A2;        // [B][nA][Nx][Ny]; A2 != null: A - A2
+    const float* Bp;            // [B][nB][Nx][Ny]
+    float* part;                // [B * bands][atiles * btiles][TA*TB*KK + TA]
+    int nA, nB, Nx, Ny, ik0, il0, lo;
+};
+
+template <int TA, int TB, int NK>
+__global__ __launch_bounds__(256) void wcorr_kernel(const WCorrArgs a)
+{
+    constexpr int PX = 4, CW = 16 * PX;                  // a stage covers 16 rows x 64 columns: PX pixels per thread between barriers
+    constexpr int TWR = 16 + NK - 1, TWC = CW + NK - 1, KK = NK * NK, NACC = TA * TB * KK;
+    __shared__ float tile[TB][TWR * TWC];
+    __shared__ float red[4][NACC + TA];
+    const int btiles = (a.nB + TB - 1) / TB;
+    const int at = blockIdx.y / btiles, bt = blockIdx.y - at * btiles;
+    const int band = blockIdx.x;
+    const long bb = blockIdx.z;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int i = band * 16 + ty;
+    const long plane = (long)a.Nx * a.Ny;
+    float acc[NACC], asum[TA];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) asum[t] = 0.f;
+    const int r0 = band * 16 - a.ik0 - (NK - 1);
+    for (int tj = 0; tj < (a.Ny + CW - 1) / CW; ++tj) {
+        const int c0 = tj * CW - a.il0 - (NK - 1);
+        __syncthreads();
+        for (int t0 = 0; t0 < TB * TWR * TWC; t0 += 256 * 8) {          // branch-free batches of 8 loads per thread
+            float v[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int t = t0 + w * 256 + threadIdx.x;
+                const int u = min(t / (TWR * TWC), TB - 1), q = t % (TWR * TWC);
+                const int b = bt * TB + u;
+                const int r = r0 + q / TWC, cc = c0 + q % TWC;
+                const bool ok = t < TB * TWR * TWC && b < a.nB && r >= a.lo && r < a.Nx && cc >= a.lo && cc < a.Ny;
+                v[w] = a.Bp[ok ? (bb * a.nB + b) * plane + (long)r * a.Ny + cc : 0];
+                if (!ok) v[w] = 0.f;
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int t = t0 + w * 256 + threadIdx.x;
+                if (t < TB * TWR * TWC) tile[t / (TWR * TWC)][t % (TWR * TWC)] = v[w];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int px = 0; px < PX; ++px) {
+            const int jl = px * 16 + tx, j = tj * CW + jl;          // consecutive lanes -> consecutive columns
+            float av[TA];
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const int ap = at * TA + t;
+                float v = 0.f;
+                if (ap < a.nA && i < a.Nx && j < a.Ny) {
+                    const long q = (bb * a.nA + ap) * plane + (long)i * a.Ny + j;
+                    v = a.A[q];
+                    if (a.A2) v -= a.A2[q];
+                }
+                av[t] = v; asum[t] += v;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int l = 0; l < NK; ++l) {
+                        const float x = tile[u][(ty + (NK - 1 - k)) * TWC + jl + (NK - 1 - l)];
+#pragma unroll
+                        for (int t = 0; t < TA; ++t) acc[(t * TB + u) * KK + k * NK + l] = fmaf(av[t], x, acc[(t * TB + u) * KK + k * NK + l]);
+                    }
+        }
+    }
+    // workgroup reduction in a fixed order
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < NACC + TA; ++e) {
+        float v = e < NACC ? acc[e < NACC ? e : 0] : asum[e >= NACC ? e - NACC : 0];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][e] = v;
+    }
+    __syncthreads();
+    float* dst = a.part + ((bb * gridDim.x + band) * gridDim.y + blockIdx.y) * (long)(NACC + TA);
+    for (int e = threadIdx.x; e < NACC + TA; e += 256) dst[e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
+
+// out[a][b][kl] = scale * sum over (frame, band) partials; bias sums from the b-tile-0 workgroups
+template <int TA, int TB, int NK>
+__global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ osum, int nA, int nB,
+                                                   int nparts, float scale)
+{
+    // one wave per output: lanes stride over the (frame, band) partials, then a shuffle tree (fixed order: deterministic)
+    constexpr int KK = NK * NK, NACC = TA * TB * KK;
+    const int atiles = (nA + TA - 1) / TA, btiles = (nB + TB - 1) / TB;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int total = nA * nB * KK;
+    if (e >= total + nA || (e >= total && !osum)) return;
+    long col;
+    if (e < total) {
+        const int kl = e % KK, b = (e / KK) % nB, ap = e / (KK * nB);
+        const int at = ap / TA, t = ap - at * TA, bt = b / TB, u = b - bt * TB;
+        col = (long)(at * btiles + bt) * (NACC + TA) + (t * TB + u) * KK + kl;
+    } else {
+        const int ap = e - total, at = ap / TA, t = ap - at * TA;
+        col = (long)(at * btiles) * (NACC + TA) + NACC + t;
+    }
+    const long stride = (long)atiles * btiles * (NACC + TA);
+    float s = 0.f;
+    for (int pidx = lane; pidx < nparts; pidx += 64) s += part[pidx * stride + col];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) { if (e < total) out[e] = s * scale; else osum[e - total] = s * scale; }
+}
+
+template <int TA, int TB, int NK>
+static hipError_t run_wcorr(const WCorrArgs& a, int B, float* out, float* osum, float scale, hipStream_t st)
+{
+    const int bands = (a.Nx + 15) / 16, atiles = (a.nA + TA - 1) / TA, btiles = (a.nB + TB - 1) / TB;
+    wcorr_kernel<TA, TB, NK><<<dim3(bands, atiles * btiles, B), 256, 0, st>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int total = a.nA * a.nB * NK * NK + a.nA;
+    wsum_kernel<TA, TB, NK><<<dim3((total + 3) / 4), 256, 0, st>>>(a.part, out, osum, a.nA, a.nB, bands * B, scale);
+    return hipGetLastError();
+}
+// tile shapes: few A planes x few B planes such that TA*TB*NK*NK accumulators stay in registers
+template <int NK> struct WTile;
+template <> struct WTile<3> { static constexpr int TA = 2, TB = 3; };
+template <> struct WTile<5> { static constexpr int TA = 1, TB = 2; };
+template <> struct WTile<7> { static constexpr int TA = 1, TB = 1; };
+template <int NK> static size_t wcorr_part_floats(int nA, int nB, int Nx, int B)
+{
+    constexpr int TA = WTile<NK>::TA, TB = WTile<NK>::TB;
+    return (size_t)B * ((Nx + 15) / 16) * ((nA + TA - 1) / TA) * ((nB + TB - 1) / TB) * (TA * TB * NK * NK + TA);
+}
+size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl)
+{
+    if (!dconv_ok(Nk, Nl, B)) return 0;
+    size_t x = 0;
+    if (Nk == 3) x = std::max(wcorr_part_floats<3>(dM, dD, Nx, B), wcorr_part_floats<3>(dD, dM, Nx, B));
+    else if (Nk == 5) x = std::max(wcorr_part_floats<5>(dM, dD, Nx, B), wcorr_part_floats<5>(dD, dM, Nx, B));
+    else x = std::max(wcorr_part_floats<7>(dM, dD, Nx, B), wcorr_part_floats<7>(dD, dM, Nx, B));
+    return x;
+}
+template <int NK> static hipError_t launch_wcorr(const WCorrArgs& a, int B, float* out, float* osum, float scale, hipStream_t st)
+{
+    return run_wcorr<WTile<NK>::TA, WTile<NK>::TB, NK>(a, B, out, osum, scale, st);
+}
+
 hipError_t launch_conv_spatial(const float* in, float* out, const float* c, const float* b, int B, int dD, int dM,
                                int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st)
 {
     const long total = (long)B * dM * Nx * Ny;
     if (total <= 0) return hipSuccess;
+    if (dconv_ok(Nk, Nl, B) && !getenv("AEFFT_NOTILEDSPATIAL")) {
+        DConvArgs a{};
+        a.in = in; a.w = c; a.bias = b; a.out = out;
+        a.Din = dD; a.M = dM; a.Nx = Nx; a.Ny = Ny; a.w_m = dD * Nk * Nl; a.w_d = Nk * Nl;
+        a.ik0 = -2 * ak - 1; a.il0 = -2 * al - 1; a.sgn = -1; a.lo_in = lo; a.hi_lo = 0; a.div = in_scale_div;
+        return launch_dconv(a, Nk, B, st);
+    }
     conv_spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(in, out, c, b, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, in_scale_div, lo);
     return hipGetLastError();
 }
@@ -141,6 +419,22 @@ __global__ __launch_bounds__(256) void bgrad_kernel(const SpatialGradArgs a)
 
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
 {
+    if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !getenv("AEFFT_NOTILEDSPATIAL")) {
+        // g = back-convolution of s0 = out - in through f (zero for i' < lo or j' < lo)
+        DConvArgs g{};
+        g.in = a.out; g.in2 = a.in; g.w = a.f; g.bias = nullptr; g.out = a.ws;
+        g.Din = a.dD; g.M = a.dM; g.Nx = a.Nx; g.Ny = a.Ny; g.w_m = a.Nk * a.Nl; g.w_d = a.dM * a.Nk * a.Nl;
+        g.ik0 = -2 * a.ak - 1; g.il0 = -2 * a.al - 1; g.sgn = +1; g.lo_in = 0; g.hi_lo = a.lo; g.div = 1.f;
+        hipError_t e = launch_dconv(g, a.Nk, a.B, st);
+        if (e != hipSuccess) return e;
+        const float scale = 1.0f / a.Norm / (float)a.B;
+        WCorrArgs wc{a.ws, nullptr, a.in, a.part, a.dM, a.dD, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, a.lo};       // dC, dB
+        WCorrArgs wf{a.out, a.in, a.hin, a.part, a.dD, a.dM, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, a.lo};        // dF, dP
+        if (a.Nk == 3) { e = launch_wcorr<3>(wc, a.B, a.gc, a.gb, scale, st); if (e == hipSuccess) e = launch_wcorr<3>(wf, a.B, a.gf, a.gp, scale, st); }
+        else if (a.Nk == 5) { e = launch_wcorr<5>(wc, a.B, a.gc, a.gb, scale, st); if (e == hipSuccess) e = launch_wcorr<5>(wf, a.B, a.gf, a.gp, scale, st); }
+        else { e = launch_wcorr<7>(wc, a.B, a.gc, a.gb, scale, st); if (e == hipSuccess) e = launch_wcorr<7>(wf, a.B, a.gf, a.gp, scale, st); }
+        return e;
+    }
     const long total = (long)a.B * a.dM * a.Nx * a.Ny;
     backconv_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(a);
     hipError_t e = hipGetLastError();

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""dev tool: time the spatial-mode kernels (Conv_gpu / backprop_gpu semantics) at the reference's default shape."""
+import importlib, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+aefft = importlib.import_module("autoencoder-fft_amd")
+ctx = aefft.Context(0)
+B, dD, dM, N, Nk = int(os.environ.get("B", "32")), 3, int(os.environ.get("M", "50")), int(os.environ.get("N", "256")), int(os.environ.get("NK", "3"))
+rng = np.random.default_rng(0)
+x = ctx.dev(np.floor(rng.uniform(0, 256, (B, dD, N, N))))
+c = ctx.dev(rng.uniform(-1, 1, (dM, dD, Nk, Nk))); b = ctx.dev(rng.uniform(-1, 1, dM))
+f = ctx.dev(rng.uniform(-1, 1, (dD, dM, Nk, Nk))); p = ctx.dev(rng.uniform(-1, 1, dD))
+ctx.prof_enable(True)
+for it in range(3):
+    ctx.prof_reset()
+    h = ctx.conv_spatial(x, c, b)
+    o = ctx.conv_spatial(h, f, p)
+    mom = [torch.zeros_like(t) for t in (c, b, f, p)]
+    grads = [torch.zeros_like(t) for t in (c, b, f, p)]
+    ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
+    pr = ctx.prof_read()
+print({k: round(v["ms"] * 1e3, 1) for k, v in pr.items() if v["launches"]})
+flops_conv = 2.0 * B * dM * dD * Nk * Nk * N * N
+print(f"conv flops {flops_conv/1e9:.2f} GF each")
