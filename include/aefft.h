@@ -164,11 +164,16 @@ int aefft_net_train_pair(aefft_net* net, int l, int n_iter, float del0, int maxd
 
 /* One data-parallel training step = forward + ONE loop-body iteration for every pair
  * (SURVEY 8d "one frame fwd+bwd"), split so the caller can all-reduce in between:
- *   step_grad : forward, then per pair the batch-mean gradient, C2R, shrink -> packed buffer
- *               [dck | dfk | db | dp] per pair, pairs concatenated; plus per-pair pre-update MSE.
+ *   step_grad : forward (recon_d nullable: layers.back()), then per pair the batch-mean gradient of the
+ *               first loop-body iteration (fft_backproplib.cu:1454-1456: gradient_k_io on the forward's
+ *               in / out spectra, C2R, shrink_k) -> packed buffer [dck | dfk | db | dp] per pair, pairs
+ *               concatenated.
  *   (caller: all-reduce SUM of aefft_net_grad_buffer over ranks)
- *   step_apply: gradients * grad_scale (1/world_size), update, new spectra, re-forward of each
- *               pair, post-update MSE.  mse_d (nullable): [L] floats on the device.
+ *   step_apply: gradients * grad_scale (1/world_size), update (:1229-1272), new kernel spectra
+ *               (:1274-1282), post-update MSE of each pair's own re-forward (:1460-1463).
+ *               mse_d (nullable): [L] floats on the device.
+ * Same sums as the reference, re-associated; intermediate layers that the
+ * reference itself never exports (fft_l = 0) are formed on demand by aefft_net_get_layer.
  * Momentum persists across steps (reset with aefft_net_reset_momentum). */
 int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
 /* Opt-in input prefetch for pipelined training loops.  enable = 1 asserts that the frames handed to
