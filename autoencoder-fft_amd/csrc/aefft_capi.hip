@@ -1089,8 +1089,8 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         // steps ago: wait for that step's end only.
         std::swap(n->pr[0].X, n->X0alt);
         if (n->ev_end_valid[n->step_no & 1]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_end[n->step_no & 1], 0));
-        // not earlier than the previous step's weight update: ahead of that point the step is bandwidth-bound itself (its own
-        // inverse FFT runs there) and an early R2C only slows it; behind it the kernels are latency-bound and leave HBM idle
+        // not earlier than the end of the previous step's gradient half: that is where a data-parallel run waits for its
+        // all-reduce (an otherwise idle gap), and what follows on this stream (update, spectra, MSE) is latency-bound
         if (n->ev_mid_valid && !getenv("AEFFT_PREFETCH_EARLY")) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_mid, 0));
         ctx->cur = ctx->aux[1];
         const int rc = do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID2);
@@ -1559,7 +1559,6 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             hipError_t e = launch_update_group(ug, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
         }
-        if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
         hipError_t e;
         {
             Bracket br(ctx, KID_KSPEC, kbytes);
@@ -1705,6 +1704,7 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
             n->recon_pending = false;
         }
         n->have_grad = true;
+        if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
         return mark_step_point(n);
     }
     RET_IF(fork_streams(ctx));

@@ -146,8 +146,11 @@ def main():
     torch.cuda.synchronize()                                              # inputs resident before anything is timed
     mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
     dp = importlib.import_module("autoencoder-fft_amd.dp")
-    if a.prefetch:
-        net.set_input_ready(True)                                         # input R2C on a side stream (measured neutral on MI355X: the step is throughput-bound)
+    if a.prefetch or world > 1:
+        # the synthetic frames are complete in HBM before the timed region: the next step's input R2C may run on a side stream.
+        # Data-parallel runs wait for the gradient all-reduce between the two halves of a step; the prefetched R2C fills that gap
+        # (tools_gap.py: -15 us per step with a 40 us gap, +7 us without one, hence off at N = 1)
+        net.set_input_ready(True)
     dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
     del0 = 0.2                                                            # autoencoder.cpp:87
 
