@@ -56,9 +56,21 @@ struct DevBuf {
     explicit DevBuf(size_t count) : n(count) { hchk(hipMalloc(&d, std::max<size_t>(count, 4) * sizeof(float)), "hipMalloc"); }
     ~DevBuf() { if (d) (void)hipFree(d); }
     DevBuf(const DevBuf&) = delete;
-    void up(const std::vector<float>& h) { hchk(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice), "H2D"); }
-    void down(std::vector<float>& h) { aefft_sync(context()); hchk(hipMemcpy(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H"); }
-    void zero() { hchk(hipMemset(d, 0, n * sizeof(float)), "memset"); }
+    // All traffic goes through the context's own (non-blocking) stream: a hipMemcpy / hipMemset on the NULL stream is NOT ordered
+    // against kernels on a non-blocking stream, and a pageable H2D copy may return before its DMA has landed -- the kernels
+    // of the same call could otherwise read the buffer before the data is there (seen as rare run-to-run differences).
+    static hipStream_t stream() { return static_cast<hipStream_t>(aefft_stream(context())); }
+    void up(const std::vector<float>& h)
+    {
+        hchk(hipMemcpyAsync(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, stream()), "H2D");
+        hchk(hipStreamSynchronize(stream()), "H2D sync");                // the host vector may be a temporary
+    }
+    void down(std::vector<float>& h)
+    {
+        hchk(hipMemcpyAsync(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost, stream()), "D2H");
+        hchk(hipStreamSynchronize(stream()), "D2H sync");
+    }
+    void zero() { hchk(hipMemsetAsync(d, 0, n * sizeof(float), stream()), "memset"); }
 };
 
 std::vector<float> flat3(const Maps& t)
