@@ -81,6 +81,7 @@ static int ws_get(aefft_ctx* ctx, int slot, size_t bytes, void** out)
         size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&ctx->ws[slot], want);
         if (e != hipSuccess) return fail(ctx, AEFFT_ENOMEM, "hipMalloc(workspace)", e);
+        if (getenv("AEFFT_POISON")) { HIPCHK(ctx, hipMemset(ctx->ws[slot], 0xFF, want)); HIPCHK(ctx, hipDeviceSynchronize()); }   // NaN-fill: uninitialised reads show up in the tests
         ctx->ws_bytes[slot] = want;
     }
     *out = ctx->ws[slot];
@@ -843,6 +844,7 @@ static int net_alloc(aefft_net* n, void** p, size_t bytes)
 {
     hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
     if (e != hipSuccess) return fail(n->ctx, AEFFT_ENOMEM, "hipMalloc(net)", e);
+    if (getenv("AEFFT_POISON")) { (void)hipMemset(*p, 0xFF, std::max<size_t>(bytes, 256)); (void)hipDeviceSynchronize(); }
     n->allocs.push_back(*p);
     return AEFFT_OK;
 }

@@ -53,7 +53,11 @@ void hchk(hipError_t e, const char* where) { if (e != hipSuccess) die(where, hip
 // device buffer with host marshalling
 struct DevBuf {
     float* d = nullptr; size_t n = 0;
-    explicit DevBuf(size_t count) : n(count) { hchk(hipMalloc(&d, std::max<size_t>(count, 4) * sizeof(float)), "hipMalloc"); }
+    explicit DevBuf(size_t count) : n(count)
+    {
+        hchk(hipMalloc(&d, std::max<size_t>(count, 4) * sizeof(float)), "hipMalloc");
+        if (getenv("AEFFT_POISON")) { hchk(hipMemset(d, 0xFF, std::max<size_t>(count, 4) * sizeof(float)), "poison"); hchk(hipDeviceSynchronize(), "poison"); }
+    }
     ~DevBuf() { if (d) (void)hipFree(d); }
     DevBuf(const DevBuf&) = delete;
     // All traffic goes through the context's own (non-blocking) stream: a hipMemcpy / hipMemset on the NULL stream is NOT ordered

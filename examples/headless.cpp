@@ -168,6 +168,9 @@ int main(int argc, char** argv)
             reset_optimizer((int)net_c[n_l].size(), (int)net_c[n_l][0].size(), (int)net_c[n_l][0][0].size(), (int)net_c[n_l][0][0][0].size());
             std::cout << "Active layer " << n_l << std::endl;
         }
+        // rand() is process-global state that the GPU runtime's threads also draw from: re-seed right before every weight
+        // initialisation so that a scripted session is reproducible (the application itself seeds with time(0), :99)
+        if (ch == 'e' || ch == 'n') srand(seed * 2654435761u + (unsigned)(t + 1));
         if (ch == 'e') {
             const size_t last = net_c.size() - 1 - n_l;
             const int dM = (int)net_c[n_l].size(), dD = (int)net_c[n_l][0].size(), k = (int)net_c[n_l][0][0].size(), l = (int)net_c[n_l][0][0][0].size();
