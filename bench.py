@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # kernel id (aefft_prof_name) -> kernel family in the rocprofv3 --pmc summaries under profiles/
+KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction, all instantiations of a step)"}
 PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "contract_kernel", "contract_lds_kernel", "contract_group_kernel"], "r2c_rows": ["r2c_rows_kernel"],
               "r2c_cols": ["fwd_cols_kernel"], "c2r_cols": ["inv_cols_kernel"], "c2r_rows": ["c2r_rows_kernel"],
               "kgrad": ["kgrad_kernel", "kgrad_group_kernel"], "kspec": ["kspec_kernel", "kspec_group_kernel"], "diff_mse": ["diff_mse_kernel"]}
@@ -194,7 +195,7 @@ def main():
         per_launch_bytes = dom["bytes"] / dom["launches"]
         avg_s = dom["ms"] / dom["launches"] * 1e-3
         ach = per_launch_bytes / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        roof = {"bound": "hbm", "kernel": KERNEL_NAMES.get(name, name), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(a.variant, name) if (a.size == 512 and a.batch == 32) else None, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 3,
                 "algo_bytes_per_launch": per_launch_bytes, "share_of_kernel_time": dom["ms"] / tot,
                 "kernels": {k: {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] / 3,
