@@ -52,6 +52,7 @@ SIGNATURES = {
     "aefft_mse": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i]),
     "aefft_update": (_i, [_vp] + [_fp] * 14 + [_i] * 6 + [_f, _i]),
     "aefft_conv_spatial": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "aefft_pool_spatial": (_i, [_vp, _fp, _fp, C.c_long, _i, _i, _i, _i, _i]),
     "aefft_backprop_spatial": (_i, [_vp] + [_fp] * 15 + [_i] * 7 + [_f, _f, _i, _i]),
     "aefft_net_create": (_i, [_vp, C.POINTER(NetDesc), C.POINTER(_vp)]),
     "aefft_net_destroy": (None, [_vp]),
@@ -248,6 +249,14 @@ class Context:
         out = self.empty(B, dM, Nx, Ny)
         self.check(self.L.aefft_conv_spatial(self.h, _ptr(x), _ptr(out), _ptr(c), _ptr(b), B, dD, dM, Nx, Ny, Nk, Nl,
                                              0 if semantics == "gpu" else 1))
+        return out
+
+    def pool_spatial(self, x, out_shape, scale):
+        """netlib.cpp Pool on the device: x [..., Nxi, Nyi] -> zeros(out_shape) filled where the reference writes."""
+        import torch
+        out = torch.zeros(tuple(x.shape[:-2]) + tuple(out_shape), dtype=torch.float32, device=x.device)
+        planes = int(np.prod(x.shape[:-2]))
+        self.check(self.L.aefft_pool_spatial(self.h, _ptr(x), _ptr(out), planes, x.shape[-2], x.shape[-1], out_shape[0], out_shape[1], scale))
         return out
 
     def backprop_spatial(self, x, out, hin, c, b, f, p, mom, grads, delmax, alpha, tied=False, semantics="gpu"):

@@ -731,6 +731,16 @@ extern "C" int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_
     return AEFFT_OK;
 }
 
+extern "C" int aefft_pool_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale)
+{
+    if (!ctx || !in_d || !out_d || planes <= 0 || Nxi <= 0 || Nyi <= 0 || Nxo <= 0 || Nyo <= 0 || scale == 0)
+        return fail(ctx, AEFFT_EINVAL, "aefft_pool_spatial: bad argument");
+    Bracket br(ctx, KID_SPATIAL, (double)planes * ((double)Nxi * Nyi + (double)Nxo * Nyo) * 4.0);
+    hipError_t e = launch_pool_spatial(in_d, out_d, planes, Nxi, Nyi, Nxo, Nyo, scale, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "pool_spatial", e);
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
                                       float* c_d, float* b_d, float* f_d, float* p_d,
                                       float* dc_d, float* db_d, float* df_d, float* dp_d,

@@ -417,6 +417,41 @@ __global__ __launch_bounds__(256) void bgrad_kernel(const SpatialGradArgs a)
     if (threadIdx.x == 0) (isP ? a.gp : a.gb)[ch] = s / a.Norm / (float)a.B;
 }
 
+// Pool (netlib.cpp:114-164) on the device.  scale > 0: window maximum through the reference's `int smax = 0` accumulator, i.e.
+// max(0, trunc(max of the window)) (the running truncation of :127-136 is order-independent: an element only replaces smax
+// when it exceeds it, and the window maximum always ends it at trunc(max)); scale < 0: nearest-neighbour up-sampling.
+__global__ __launch_bounds__(256) void pool_spatial_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                           int Nxi, int Nyi, int Nxo, int Nyo, int scale)
+{
+    const long total = planes * Nxo * Nyo;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= total) return;
+    const int jo = (int)(n % Nyo), io = (int)((n / Nyo) % Nxo);
+    const long d = n / ((long)Nxo * Nyo);
+    const float* src = in + d * Nxi * Nyi;
+    if (scale > 0) {
+        const int i0 = io * scale, j0 = jo * scale;
+        if (i0 >= Nxi || j0 >= Nyi) return;                 // the reference loop never reaches these outputs: left untouched
+        float mx = 0.f;
+        for (int k = 0; k < scale; ++k)
+            for (int l = 0; l < scale; ++l)
+                if (i0 + k < Nxi && j0 + l < Nyi) mx = fmaxf(mx, src[(long)(i0 + k) * Nyi + j0 + l]);
+        out[n] = (float)(int)mx;
+    } else {
+        const int s = -scale;
+        if (io / s >= Nxi || jo / s >= Nyi) return;
+        out[n] = src[(long)(io / s) * Nyi + jo / s];
+    }
+}
+
+hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale, hipStream_t st)
+{
+    const long total = planes * Nxo * Nyo;
+    if (total <= 0 || scale == 0) return scale == 0 ? hipErrorInvalidValue : hipSuccess;
+    pool_spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(in, out, planes, Nxi, Nyi, Nxo, Nyo, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
 {
     if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !getenv("AEFFT_NOTILEDSPATIAL")) {

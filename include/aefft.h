@@ -108,6 +108,10 @@ int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, float* p_d,
  * instead (ak=(Nk-1)/2-1, boundary test '>0', no division). */
 int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, const float* c_d, const float* b_d,
                        int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl, int cpu_semantics);
+/* netlib.cpp:114-164 `Pool` on the device: scale > 0 pools scale x scale windows through the reference's
+ * integer accumulator (`int smax = 0`: result = max(0, trunc(window maximum)), also at scale 1); scale < 0 up-samples by
+ * nearest neighbour.  in_d [planes][Nxi][Nyi] -> out_d [planes][Nxo][Nyo]; outputs the reference loop never writes stay untouched. */
+int aefft_pool_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale);
 /* backproplib.cu:291-418 `backprop_gpu` (tied=0) / :521-644 `backprop_gpu_cc` (tied=1): back-conv
  * through f + weight-gradient correlation, then the inertia update
  *   d <- (1-alpha)*delmax*g/max(10,|g|) + alpha*d ; w <- w - d     (:392-396)

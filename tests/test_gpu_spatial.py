@@ -92,3 +92,20 @@ def test_gradient_cpu_semantics_vs_compiled_reference(ctx):
     assert np.abs(host(tg[0]) - ref).max() < 1e-4 * np.abs(ref).max()
     refb = -b2.astype(np.float64) * 10 / dele
     assert np.abs(host(tg[1]) - refb).max() < 1e-4 * np.abs(refb).max()
+
+
+@pytest.mark.parametrize("N,scale", [(32, 2), (33, 2), (20, 4), (16, 1), (16, -2), (9, -3)])
+def test_pool_on_device_is_bit_identical_to_the_reference_pool(ctx, N, scale):
+    """aefft_pool_spatial == netlib.cpp Pool (compiled reference when present, else its C port): integer accumulator
+    (truncation, clamp at 0, also at scale 1) going down, nearest neighbour going up; ragged sizes included."""
+    L = cpu.reference() or cpu.port()
+    rng = np.random.default_rng(100 + N + scale)
+    D = 3
+    x = (rng.uniform(-40, 260, (D, N, N))).astype(np.float32)
+    if scale > 0:
+        shape = (D, (N + scale - 1) // scale, (N + scale - 1) // scale)
+    else:
+        shape = (D, N * -scale, N * -scale)
+    ref = L.pool(x, shape, scale)
+    got = host(ctx.pool_spatial(ctx.dev(x), shape[1:], scale))
+    assert np.array_equal(got, ref)
