@@ -100,3 +100,20 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
         assert np.abs(got_b - bias).max() < tol, (n, np.abs(got_b - bias).max(), tol)
     got_out = final[off:].reshape(D, N, N)
     assert np.abs(got_out - lay_end[-1]).max() < 1e-3 * np.abs(lay_end[-1]).max() + 50 * slack1 * np.abs(lay_end[-1]).max()
+
+
+def test_driver_fails_loudly_without_a_device(tmp_path):
+    """No GPU in this process' environment => the vector API aborts with a message (there is no CPU fallback to hide behind)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a device is present")
+    except ImportError:
+        pass
+    if not os.path.exists(DRIVER):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "autoencoder-fft_amd", "csrc"), "headless"])
+    with open(os.path.join(str(tmp_path), "New_Layer_Param.txt"), "w") as fh:
+        fh.write("M 4\nLk 1\nLl 1\nS 2\nrmax 1\n")
+    out = subprocess.run([DRIVER, "--size", "32", "--frames", "1", "--script", "."], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "no CPU fallback" in out.stderr
