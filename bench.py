@@ -53,8 +53,8 @@ def pmc_traffic(variant, kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (weak scaling)")
     ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
     ap.add_argument("--size", type=int, default=512)
