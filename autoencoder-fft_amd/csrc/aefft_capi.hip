@@ -247,10 +247,20 @@ static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nx
     return AEFFT_OK;
 }
 
+// algorithmic bytes of one contraction = UNIQUE tensors entering + leaving: A (R*K planes) + B (K*C planes) + Out (R*C planes),
+// 8 B per bin; an operand that is the same tensor as another one (X X^H; the MSE epilogue's T = B) counts once; A2 counts.
+static double contract_bytes(const Contract& q)
+{
+    const bool self = q.A == q.B && q.a_r == q.b_c && q.a_k == q.b_k && q.R == q.C;
+    double planes = (double)q.R * q.K + (self ? 0.0 : (double)q.K * q.C);
+    if (q.A2 && q.A2 != q.B) planes += (double)q.R * q.K;
+    if (!q.mse.acc) planes += (double)q.R * q.C;
+    return planes * q.P * 8.0;
+}
+
 static int do_contract(aefft_ctx* ctx, const Contract& q)
 {
-    // algorithmic bytes: A (R*K planes) + B (K*C planes) + Out (R*C planes), 8 B per bin
-    const double bytes = ((double)q.R * q.K + (double)q.K * q.C + (double)q.R * q.C) * q.P * 8.0;
+    const double bytes = contract_bytes(q);
     Bracket br(ctx, KID_CONTRACT, bytes);
     hipError_t e = launch_contract(q, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract", e);
@@ -259,8 +269,7 @@ static int do_contract(aefft_ctx* ctx, const Contract& q)
 
 static int do_contract2(aefft_ctx* ctx, const Contract& q0, const Contract& q1)
 {
-    const double bytes = (((double)q0.R * q0.K + (double)q0.K * q0.C + (double)q0.R * q0.C) * q0.P +
-                          ((double)q1.R * q1.K + (double)q1.K * q1.C + (double)q1.R * q1.C) * q1.P) * 8.0;
+    const double bytes = contract_bytes(q0) + contract_bytes(q1);
     Contract2 qq{};
     qq.q[0] = q0; qq.q[1] = q1; qq.n = 2;
     Bracket br(ctx, KID_CONTRACT, bytes);
@@ -374,7 +383,7 @@ static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, 
     if (n <= 8 && n > 1 && !nogroup) {
         ContractN g{};
         double bytes = 0;
-        for (int i = 0; i < n; ++i) { g.q[i] = qs[i]; bytes += ((double)qs[i].R * qs[i].K + (double)qs[i].K * qs[i].C + (double)qs[i].R * qs[i].C) * qs[i].P * 8.0 * (qs[i].A2 ? 1.0 : 1.0); }
+        for (int i = 0; i < n; ++i) { g.q[i] = qs[i]; bytes += contract_bytes(qs[i]); }
         g.n = n; g.nA = nA;
         hipError_t e;
         {
@@ -1529,7 +1538,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_i
         const Contract m = mk_gmse(q.G, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
         hipError_t e;
         {
-            Bracket br(ctx, KID_CONTRACT, ((double)m.R * m.K + 2.0 * m.K * m.C) * m.P * 8.0);
+            Bracket br(ctx, KID_CONTRACT, contract_bytes(m));
             e = launch_contract(m, ctx->cur);
         }
         if (e == hipSuccess) { if (g_left_in_S) *g_left_in_S = true; return AEFFT_OK; }
@@ -1647,7 +1656,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             if (!gtaps) RET_IF(do_contract_group(ctx, gq, m, m, 0));
             ContractN g{};
             double bytes = 0;
-            for (int i = 0; i < m; ++i) { g.q[i] = mq[i]; bytes += ((double)mq[i].R * mq[i].K + 2.0 * mq[i].K * mq[i].C) * mq[i].P * 8.0; }
+            for (int i = 0; i < m; ++i) { g.q[i] = mq[i]; bytes += contract_bytes(mq[i]); }
             g.n = m;
             hipError_t e;
             {
