@@ -211,22 +211,38 @@ def test_step_equals_oracle_batch_iteration(ctx, B, path, monkeypatch):
     (or forces one that the small test shapes would not choose) so that its fallback is exercised too."""
     if path:
         monkeypatch.setenv(path, "1")
-    rng = np.random.default_rng(77 + B)
-    D, N, maps, Nk, s = 3, 32, [4, 6], 5, 2
+    _step_vs_oracle(ctx, np.random.default_rng(77 + B), B, 3, 32, 32, [4, 6], 5, 2)
+
+
+@pytest.mark.parametrize("D,Nx,Ny,maps,Nk,s,B", [
+    (3, 32, 32, [4, 6], 3, 2, 2),          # 3x3 kernels: 5x5 offsets in the Q path
+    (3, 32, 32, [4], 7, 2, 2),             # 7x7 kernels: no Q path (dc|df spectra route), single pair
+    (1, 32, 64, [5, 3], 5, 2, 3),          # non-square planes, gray input, odd map counts
+    (3, 64, 64, [4, 6, 5], 5, 2, 2),       # three pairs: decoder chain on the coarsest support
+    (3, 32, 32, [4, 6], 5, 1, 2),          # no pooling: nothing to compact, classic S
+    (2, 64, 32, [3, 9], 3, 2, 5),          # B not a multiple of 4, Nx > Ny
+])
+def test_step_shapes_vs_oracle(ctx, D, Nx, Ny, maps, Nk, s, B):
+    """the same comparison across kernel supports, plane shapes, depths and pooling settings (edge cases of the tiled paths)"""
+    _step_vs_oracle(ctx, np.random.default_rng(5 * Nx + Ny + Nk + B), B, D, Nx, Ny, maps, Nk, s)
+
+
+def _step_vs_oracle(ctx, rng, B, D, Nx, Ny, maps, Nk, s):
+    N = Nx
     L = len(maps)
-    xs = np.floor(rng.uniform(0, 256, (B, D, N, N)))
+    xs = np.floor(rng.uniform(0, 256, (B, D, Nx, Ny)))
     ws = []
     dD = D
     for dM in maps:
         _, c, f, b, p = _pair(rng, dD, dM, 8, Nk, 1)
         ws.append((c, b, f, p)); dD = dM
-    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    net = aefft.Net(ctx, D, Nx, Ny, maps, Nk, s, batch=B)
     for l, w in enumerate(ws):
         net.set_pair(l, *w)
     net_c = [w[0] for w in ws] + [w[2] for w in ws[::-1]]
     net_b = [w[1] for w in ws] + [w[3] for w in ws[::-1]]
     sp = [R.autoenc_fft(xs[i], net_c, net_b, [s] * L + [-s] * L) for i in range(B)]
-    recon = ctx.empty(B, D, N, N)
+    recon = ctx.empty(B, D, Nx, Ny)
     net.step_grad(ctx.dev(xs), recon)
     for i in range(B):
         assert relerr(host(recon)[i], sp[i][0][-1]) < TOL
