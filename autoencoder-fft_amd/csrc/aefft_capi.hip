@@ -30,6 +30,7 @@ struct aefft_ctx {
     hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
+    bool recon_join = false;         // a deferred reconstruction (pipelined mode) still has to be joined from aux[0] (ev_join[0])
     bool concurrency = false;        // spread independent per-pair work over the side streams (measured slower on MI355X: off by default)
     static const int NAUX = 4;
     hipStream_t aux[NAUX] = {};      // side streams for independent per-pair work (created on first net)
@@ -138,7 +139,14 @@ extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
 }
 
 extern "C" const char* aefft_last_error(const aefft_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-extern "C" int aefft_sync(aefft_ctx* ctx) { if (!ctx) return AEFFT_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return AEFFT_OK; }
+static int join_recon(aefft_ctx* ctx)
+{
+    if (!ctx->recon_join) return AEFFT_OK;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+    ctx->recon_join = false;
+    return AEFFT_OK;
+}
+extern "C" int aefft_sync(aefft_ctx* ctx) { if (!ctx) return AEFFT_EINVAL; RET_IF(join_recon(ctx)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return AEFFT_OK; }
 extern "C" int aefft_ctx_set_concurrency(aefft_ctx* ctx, int enable) { if (!ctx) return AEFFT_EINVAL; ctx->concurrency = enable != 0; return AEFFT_OK; }
 extern "C" void* aefft_stream(aefft_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -852,6 +860,7 @@ struct aefft_net {
     unsigned ox_done = 0;         // bit l: the forward already launched pair l's support term S += sum_b Oc X^H
     bool xx_done = false;         // the forward already launched S = -sum_b X X^H (grouped with the innermost decoder conv)
     bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
+    float* recon_deferred = nullptr;   // pipelined mode: the reconstruction is launched at the end of the gradient half
     bool burst = false;        // inside aefft_net_train_pair (its MSE slots are zeroed up front, not by the update kernel)
     // shared scratch sized for the largest pair
     bool fuse_crop = true;     // encoder convs also write the next pair's cropped input (no resize launches)
@@ -1100,6 +1109,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     if (!n || !frames_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_forward: bad argument");
     aefft_ctx* ctx = n->ctx;
     const int B = n->B, L = n->L;
+    RET_IF(join_recon(ctx));
     n->xx_done = false; n->ox_done = 0;
     for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
@@ -1221,6 +1231,14 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         Pair& q = n->pr[0];
         const char* nooverlap = getenv("AEFFT_NOOVERLAP");
         const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
+        n->recon_deferred = nullptr;
+        if (async && n->input_ready && !getenv("AEFFT_NODEFER")) {
+            // pipelined loop (aefft_net_set_input_ready): launched by aefft_net_step_grad after the gradient half instead
+            n->recon_deferred = recon_d;
+            n->last_frames = frames_d;
+            n->have_forward = true; n->have_grad = false;
+            return AEFFT_OK;
+        }
         if (async) {
             // training step: nothing downstream reads the reconstruction, so its (bandwidth-bound) inverse FFT runs on a side
             // stream underneath the latency-bound gradient contractions; aefft_net_step_grad joins it before returning
@@ -1249,6 +1267,7 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
 {
     if (!n || layer < 0 || layer > 4 * n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_layer: bad layer index");
     aefft_ctx* ctx = n->ctx;
+    RET_IF(join_recon(ctx));
     const int L = n->L, B = n->B;
     int c, x, y, xi, yi;            // channels, output size, stored spectrum size
     const float2* S = nullptr;
@@ -1329,6 +1348,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     if (!n || l < 0 || l >= n->L || n_iter < 0) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_train_pair: bad argument");
     aefft_ctx* ctx = n->ctx;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
+    RET_IF(join_recon(ctx));
     Pair& q = n->pr[l];
     RET_IF(ensure_O(n, q));
     if ((size_t)(n_iter + 1) > n->mse_cap) {
@@ -1719,6 +1739,22 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     const bool side = use_side_streams(n);
     if (!side) {
         RET_IF(grads_grouped(n));
+        if (n->recon_deferred) {
+            // The reconstruction's inverse FFT starts HERE: where a data-parallel run waits for its all-reduce the GPU is otherwise
+            // idle, and what follows on this stream (update, spectra, MSE) is latency-bound.  Joined by aefft_net_step_apply,
+            // aefft_sync or the next call on this net.
+            Pair& q = n->pr[0];
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+            ctx->cur = ctx->aux[0];
+            const int rc = q.O_stale ? do_c2r(ctx, q.Oc, n->recon_deferred, (long)n->B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny))
+                                     : do_c2r(ctx, q.O, n->recon_deferred, (long)n->B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny));
+            ctx->cur = ctx->stream;
+            n->recon_deferred = nullptr;
+            RET_IF(rc);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+            ctx->recon_join = true;
+        }
         if (n->recon_pending) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
@@ -1759,6 +1795,7 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     if (!side) {
         RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
         n->have_grad = false;
+        RET_IF(join_recon(ctx));
         return mark_step_point(n);
     }
     RET_IF(fork_streams(ctx));
@@ -1771,5 +1808,6 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     RET_IF(rc);
     if (mse_d) HIPCHK(ctx, hipMemcpyAsync(mse_d, n->mse_post, sizeof(float) * n->L, hipMemcpyDeviceToDevice, ctx->stream));
     n->have_grad = false;
+    RET_IF(join_recon(ctx));
     return mark_step_point(n);
 }

@@ -184,7 +184,10 @@ int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
  * aefft_net_step_grad are COMPLETE in device memory when the call is made (not merely ordered on the
  * context stream, e.g. a loader that synchronises its own copy stream): their R2C then runs on an
  * internal side stream and may overlap the tail of the previous step still queued on the context
- * stream (the input spectra are double-buffered).  Default 0: everything is ordered on the context stream. */
+ * stream (the input spectra are double-buffered); and the reconstruction written by aefft_net_step_grad is
+ * launched at the END of the gradient half (where a data-parallel rank waits for its all-reduce) and is complete
+ * on the context stream only after the following aefft_net_step_apply, aefft_sync or any later call on the net.
+ * Default 0: everything is ordered on the context stream and recon_d is complete when aefft_net_step_grad's work is. */
 int aefft_net_set_input_ready(aefft_net* net, int enable);
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 int aefft_net_step_apply(aefft_net* net, float del0, int maxdiff, int sym, float grad_scale, float* mse_d);
