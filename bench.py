@@ -150,7 +150,8 @@ def main():
     if a.prefetch or world > 1:
         # the synthetic frames are complete in HBM before the timed region: the next step's input R2C may run on a side stream.
         # Data-parallel runs wait for the gradient all-reduce between the two halves of a step; the prefetched R2C fills that gap
-        # (tools_gap.py: -15 us per step with a 40 us gap, +7 us without one, hence off at N = 1)
+        # together with this step's reconstruction inverse FFT (tools_gap.py: a 40 us gap then costs +11 us per step instead of +32;
+        # without a gap the mode costs +2 us, hence off at N = 1)
         net.set_input_ready(True)
     dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
     del0 = 0.2                                                            # autoencoder.cpp:87
