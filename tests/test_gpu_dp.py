@@ -26,17 +26,19 @@ def _problem():
     return D, N, maps, Nk, s, xs, ws
 
 
-def _train(aefft, dp, frames, B, steps=2):
+def _train(aefft, dp, frames, B, steps=3, pipelined=False):
     D, N, maps, Nk, s, _, ws = _problem()
     ctx = aefft.Context(0)
     net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
     for l, w in enumerate(ws):
         net.set_pair(l, *w)
+    net.set_input_ready(pipelined)       # as bench.py does at N > 1: input R2C and reconstruction C2R move into the all-reduce gap
     step = dp.DataParallelStep(net)
     fr = ctx.dev(frames)
     mse = ctx.empty(len(maps))
+    recon = ctx.empty(*fr.shape) if pipelined else None
     for _ in range(steps):
-        step(fr, None, 0.2, 0, 0, mse)
+        step(fr, recon, 0.2, 0, 0, mse)
     ctx.sync()
     ok = step.replicas_agree()
     out = [net.get_pair(l) for l in range(len(maps))]
@@ -51,7 +53,7 @@ def _worker(rank, world, port, q):
     aefft = importlib.import_module("autoencoder-fft_amd"); dp = importlib.import_module("autoencoder-fft_amd.dp")
     xs = _problem()[5]
     per = len(xs) // world
-    out, ok = _train(aefft, dp, xs[rank * per:(rank + 1) * per], per)
+    out, ok = _train(aefft, dp, xs[rank * per:(rank + 1) * per], per, pipelined=True)
     q.put((rank, out, ok))
     dist.barrier()
     dist.destroy_process_group()
