@@ -549,163 +549,6 @@ static int contract_fast_class(const Contract2& qq)
     return -1;
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS-blocked variant for channel-heavy contractions (K >= 8, R, C >= 8: the inner pairs, where the
-// planes are small and every operand is re-used many times).  A workgroup owns BT = 32 consecutive
-// bins and an RB x CB = 16 x 16 block of outputs; the K loop runs in chunks of KC = 4 staged through
-// LDS, so each operand element is fetched from L2 once per workgroup instead of once per register
-// tile.  Eight half-waves (32 lanes = 32 bins) each own a 4 x 8 register tile; LDS reads are
-// conflict-free (a half-wave reads 256 contiguous bytes).  conj / pre-division / the fused
-// subtraction are applied when the tile is written to LDS, so the inner loop is pure complex FMA.
-// ------------------------------------------------------------------------------------------
-constexpr int LB_BT = 32, LB_RB = 16, LB_CB = 16, LB_KC = 4;
-
-__device__ __forceinline__ void contract_lds_body(const Contract& q, int bx, int by, int zblk, float2* As, float2* Bs)
-{
-    const int tid = threadIdx.x;
-    const long bin0 = (long)bx * LB_BT;
-    const int r0 = by * LB_RB, c0 = zblk * LB_CB;
-    if (r0 >= q.R || c0 >= q.C) return;             // uniform per workgroup
-    const int lane = tid & 31, grp = tid >> 5;
-    const int gr = (grp >> 1) * 4, gc = (grp & 1) * 8;
-    const long bin = bin0 + lane;
-    const float sa = q.conjA ? -1.f : 1.f, sb = q.conjB ? -1.f : 1.f;
-    const float bmul = q.preDivB != 0.f ? 1.0f / q.preDivB : 1.0f;
-    const float omul = q.postDiv != 0.f ? 1.0f / q.postDiv : 1.0f;
-
-    // zero-pad remap of the B operand: source bin of this thread's destination bin (or none)
-    long sbin = bin;
-    bool live = bin < q.P;
-    if (q.upNx && live) {
-        const int Nyr = q.upNy / 2 + 1, Nyrs = q.upNys / 2 + 1;
-        const int i = (int)(bin / Nyr), j = (int)(bin - (long)i * Nyr);
-        int si = -1, sj = -1;
-        if (i < q.upNxs / 2) si = i;
-        else if (i > q.upNx - q.upNxs / 2) si = i - q.upNx + q.upNxs;
-        else if (i == q.upNx / 2) si = q.upNxs / 2;
-        if (j < Nyrs - 1) sj = j;
-        else if (j == Nyr - 1) sj = Nyrs - 1;
-        live = (si >= 0 && sj >= 0);
-        sbin = (long)si * Nyrs + sj;
-    }
-    // a whole tile without a live bin only stores zeros (+bias): skip the K loop (workgroup-uniform vote)
-    const int any_live = __syncthreads_or(live ? 1 : 0);
-
-    float2 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = make_float2(0.f, 0.f);
-
-    if (any_live) {
-        // each thread stages 8 A and 8 B elements per K chunk: (kk, row) = segment grp + 8u of its 32-bin column.
-        // Global loads for chunk k0+KC are issued into registers BEFORE the FMAs of chunk k0 (software prefetch).
-        constexpr int NA = LB_KC * LB_RB / 8, NB = LB_KC * LB_CB / 8;
-        float2 va[NA], va2[NA], vb[NB];
-        // branch-free: every load is issued unconditionally from a clamped (always valid) address and
-        // masked afterwards -- a load inside a per-lane conditional makes hipcc wait for it at the join,
-        // which serialises the whole batch (cdna_hip_programming.md, "register or load" trap).
-        const long cbin = bin < q.P ? bin : q.P - 1;
-        const long csbin = live ? sbin : 0;
-        const bool hasA2 = q.A2 != nullptr;
-        const float2* A2p = hasA2 ? q.A2 : q.A;
-        auto fetch = [&](int k0) {
-#pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int seg = grp + 8 * u, kk = seg / LB_RB, r = seg - kk * LB_RB;
-                const int kq = (k0 + kk < q.K) ? k0 + kk : q.K - 1;
-                const int rr = (r0 + r < q.R) ? r0 + r : q.R - 1;
-                const long off = rr * q.a_r + kq * q.a_k + cbin;
-                va[u] = q.A[off];
-                if (hasA2) va2[u] = A2p[off];
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int seg = grp + 8 * u, kk = seg / LB_CB, c = seg - kk * LB_CB;
-                const int kq = (k0 + kk < q.K) ? k0 + kk : q.K - 1;
-                const int cc = (c0 + c < q.C) ? c0 + c : q.C - 1;
-                vb[u] = q.B[kq * q.b_k + cc * q.b_c + csbin];
-            }
-        };
-        fetch(0);
-        for (int k0 = 0; k0 < q.K; k0 += LB_KC) {
-#pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int kk = (grp + 8 * u) / LB_RB;
-                float2 v = va[u];
-                if (hasA2) { v.x -= va2[u].x; v.y -= va2[u].y; }
-                v.y *= sa;
-                if (!(k0 + kk < q.K && bin < q.P)) v = make_float2(0.f, 0.f);
-                As[(grp + 8 * u) * LB_BT + lane] = v;
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int kk = (grp + 8 * u) / LB_CB;
-                float2 v = vb[u];
-                v.x *= bmul; v.y *= bmul * sb;
-                if (!(k0 + kk < q.K && live)) v = make_float2(0.f, 0.f);
-                Bs[(grp + 8 * u) * LB_BT + lane] = v;
-            }
-            __syncthreads();
-            if (k0 + LB_KC < q.K) fetch(k0 + LB_KC);
-#pragma unroll
-            for (int kk = 0; kk < LB_KC; ++kk) {
-                float2 a[4], b[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = As[(kk * LB_RB + gr + i) * LB_BT + lane];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[j] = Bs[(kk * LB_CB + gc + j) * LB_BT + lane];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) cfma(acc[i][j], a[i], b[j]);
-            }
-            __syncthreads();
-        }
-    }
-    if (bin >= q.P) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = r0 + gr + i, c = c0 + gc + j;
-            if (r >= q.R || c >= q.C) continue;
-            float2 val = acc[i][j];
-            if (q.bias && bin == 0) val.x += q.bias[r] * q.biasScale;
-            val.x *= omul; val.y *= omul;
-            q.Out[r * q.o_r + c * q.o_c + bin] = val;
-            if (q.Out2) {
-                const long db = crop_dest(bin, q.dnNx, q.dnNy, q.dnNxs, q.dnNys);
-                if (db >= 0) q.Out2[((r * q.o_r + c * q.o_c) / q.P) * ((long)q.dnNxs * (q.dnNys / 2 + 1)) + db] = val;
-            }
-        }
-}
-
-__global__ __launch_bounds__(256) void contract_lds_kernel(const Contract2 qq, int gx, int gy, int gz, int z0)
-{
-    __shared__ float2 As[LB_KC * LB_RB * LB_BT];
-    __shared__ float2 Bs[LB_KC * LB_CB * LB_BT];
-    const BlockId b = xcd_decode(gx, gy, gz);
-    if (!b.ok) return;
-    if (b.bz < z0) contract_lds_body(qq.q[0], b.bx, b.by, b.bz, As, Bs);
-    else contract_lds_body(qq.q[1], b.bx, b.by, b.bz - z0, As, Bs);
-}
-
-static bool contract_wants_lds(const Contract& q) { return q.K >= 16 && q.R >= 8 && q.C >= 8; }
-
-static hipError_t contract_lds_launch(const Contract2& qq, hipStream_t st)
-{
-    long gx = 0; int gy = 0, z[2] = {0, 0};
-    for (int p = 0; p < qq.n; ++p) {
-        const Contract& q = qq.q[p];
-        gx = std::max(gx, (q.P + LB_BT - 1) / LB_BT);
-        gy = std::max(gy, (q.R + LB_RB - 1) / LB_RB);
-        z[p] = (q.C + LB_CB - 1) / LB_CB;
-    }
-    contract_lds_kernel<<<dim3(xcd_grid(gx, gy, z[0] + z[1])), 256, 0, st>>>(qq, (int)gx, gy, z[0] + z[1], z[0]);
-    return hipGetLastError();
-}
-
 static bool contract_even(const Contract& q)
 {
     return !((q.P & 1) || (q.a_r & 1) || (q.a_k & 1) || (q.b_k & 1) || (q.b_c & 1) || (q.o_r & 1) || (q.o_c & 1)) && !q.upNx;
@@ -730,12 +573,6 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
         if (e != hipErrorInvalidValue) return e;
     }
     for (int p = 0; p < qq.n; ++p) if (qq.q[p].gdNx) return hipErrorInvalidValue;     // gather form: matrix-core kernel only
-    static const char* force = getenv("AEFFT_CONTRACT");     // dev switch: reg | lds
-    bool lds = true;
-    for (int p = 0; p < qq.n; ++p) lds = lds && contract_wants_lds(qq.q[p]);
-    lds = false;                                                // measured slower than the lean register kernel on MI355X
-    if (force && force[0] == 'l') lds = true;
-    if (lds) return contract_lds_launch(qq, st);
     // start from the largest register tile the shapes allow and shrink until the launch has enough waves
     int tr = Rmin >= 4 ? 4 : (Rmin >= 2 ? 2 : 1), tc = Cmin >= 4 ? 4 : (Cmin >= 2 ? 2 : 1), vec = even ? 2 : 1;
     auto waves = [&](int v, int r, int c) {

@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # kernel id (aefft_prof_name) -> kernel family in the rocprofv3 --pmc summaries under profiles/
 KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction, all instantiations of a step)"}
-PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "contract_kernel", "contract_lds_kernel", "contract_group_kernel"], "r2c_rows": ["r2c_rows_kernel"],
+PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "contract_kernel", "contract_group_kernel"], "r2c_rows": ["r2c_rows_kernel"],
               "r2c_cols": ["fwd_cols_kernel"], "c2r_cols": ["inv_cols_kernel"], "c2r_rows": ["c2r_rows_kernel"],
               "kgrad": ["kgrad_kernel", "kgrad_group_kernel"], "kspec": ["kspec_kernel", "kspec_group_kernel"], "diff_mse": ["diff_mse_kernel"]}
 
