@@ -141,6 +141,9 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
         };
         int k0 = kbeg;
         for (; k0 + UNR <= kend; k0 += UNR) group(k0, std::integral_constant<int, UNR>{});
+        // remainder in halving groups (4, 2, 1) instead of one iteration -- one memory round trip -- at a time
+        if (UNR >= 8 && k0 + 4 <= kend) { group(k0, std::integral_constant<int, 4>{}); k0 += 4; }
+        if (UNR >= 4 && k0 + 2 <= kend) { group(k0, std::integral_constant<int, 2>{}); k0 += 2; }
         for (; k0 < kend; ++k0) group(k0, std::integral_constant<int, 1>{});
     }
     if (KS > 1) {
