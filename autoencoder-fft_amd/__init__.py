@@ -18,6 +18,12 @@ LIB_PATH = os.path.join(_HERE, "libaefft.so")
 OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 
 
+# include/aefft.h AEFFT_F_* (development switches; tests/test_abi.py checks this table against the header)
+FLAGS = {n: 1 << i for i, n in enumerate(
+    ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
+     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOGRAPH"])}
+
+
 class AefftError(RuntimeError):
     pass
 
@@ -37,7 +43,8 @@ SIGNATURES = {
     "aefft_ctx_destroy": (None, [_vp]),
     "aefft_last_error": (C.c_char_p, [_vp]),
     "aefft_sync": (_i, [_vp]),
-    "aefft_ctx_set_concurrency": (_i, [_vp, _i]),
+    "aefft_ctx_set_flags": (_i, [_vp, C.c_uint]),
+    "aefft_ctx_get_flags": (C.c_uint, [_vp]),
     "aefft_stream": (_vp, [_vp]),
     "aefft_version": (C.c_char_p, []),
     "aefft_r2c": (_i, [_vp, _fp, _fp, _l, _i, _i]),
@@ -270,8 +277,16 @@ class Context:
                                                  B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, 1 if tied else 0,
                                                  0 if semantics == "gpu" else 1))
 
-    def set_concurrency(self, on=True):
-        self.check(self.L.aefft_ctx_set_concurrency(self.h, 1 if on else 0))
+    def set_flags(self, *names):
+        """Development switches (include/aefft.h AEFFT_F_*), by name without the prefix; no names = defaults."""
+        v = 0
+        for nme in names:
+            if nme:
+                v |= FLAGS[nme.replace("AEFFT_", "").replace("F_", "")]
+        self.check(self.L.aefft_ctx_set_flags(self.h, v))
+
+    def get_flags(self):
+        return int(self.L.aefft_ctx_get_flags(self.h))
 
     # ---- profiling ----
     def prof_enable(self, on=True):

@@ -15,7 +15,7 @@ using namespace aefft;
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_PART = 10, WS_MID2 = 11, WS_COUNT = 12 };
+enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF = 6, WS_SMALL = 7, WS_DEN = 8, WS_TMP = 9, WS_PART = 10, WS_MID2 = 11, WS_MID3 = 12, WS_COUNT = 13 };
 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
@@ -31,9 +31,8 @@ struct aefft_ctx {
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
     bool recon_join = false;         // a deferred reconstruction (pipelined mode) still has to be joined from aux[0] (ev_join[0])
-    bool concurrency = false;        // spread independent per-pair work over the side streams (measured slower on MI355X: off by default)
-    static const int NAUX = 4;
-    hipStream_t aux[NAUX] = {};      // side streams for independent per-pair work (created on first net)
+    static const int NAUX = 2;
+    hipStream_t aux[NAUX] = {};      // side streams: 0 = reconstruction inverse FFT, 1 = input prefetch (created with the first net)
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {};
     std::string err;
     const float2* tw = nullptr;      // device twiddle table
@@ -82,7 +81,7 @@ static int ws_get(aefft_ctx* ctx, int slot, size_t bytes, void** out)
         size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&ctx->ws[slot], want);
         if (e != hipSuccess) return fail(ctx, AEFFT_ENOMEM, "hipMalloc(workspace)", e);
-        if (getenv("AEFFT_POISON")) { HIPCHK(ctx, hipMemset(ctx->ws[slot], 0xFF, want)); HIPCHK(ctx, hipDeviceSynchronize()); }   // NaN-fill: uninitialised reads show up in the tests
+        if (flag(AEFFT_F_POISON)) { HIPCHK(ctx, hipMemset(ctx->ws[slot], 0xFF, want)); HIPCHK(ctx, hipDeviceSynchronize()); }   // NaN-fill: uninitialised reads show up in the tests
         ctx->ws_bytes[slot] = want;
     }
     *out = ctx->ws[slot];
@@ -103,12 +102,40 @@ struct Bracket {
     ~Bracket() { if (idx >= 0) (void)hipEventRecord(ctx->pool[idx].b, ctx->cur); }
 };
 
-extern "C" const char* aefft_version(void) { return "aefft 0.1 (gfx950)"; }
+namespace aefft { unsigned dev_flags = 0; }
+static const struct { const char* name; unsigned bit; } flag_names[] = {
+    {"NOLAZY", AEFFT_F_NOLAZY}, {"NOCOMPACT", AEFFT_F_NOCOMPACT}, {"NOQPATH", AEFFT_F_NOQPATH}, {"NOFUSEMSE", AEFFT_F_NOFUSEMSE},
+    {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
+    {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
+    {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOGRAPH", AEFFT_F_NOGRAPH}};
+static void flags_from_env_once()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("AEFFT_FLAGS");           // the ONLY environment lookup of the library
+    if (!e) return;
+    std::string s(e);
+    size_t i = 0;
+    while (i <= s.size()) {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        const std::string w = s.substr(i, j - i);
+        for (const auto& f : flag_names) if (w == f.name) dev_flags |= f.bit;
+        i = j + 1;
+    }
+}
+extern "C" int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags) { if (!ctx) return AEFFT_EINVAL; dev_flags = flags; return AEFFT_OK; }
+extern "C" unsigned aefft_ctx_get_flags(const aefft_ctx*) { return dev_flags; }
+
+extern "C" const char* aefft_version(void) { return "aefft 0.2 (gfx950)"; }
 
 extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, int create_stream)
 {
     if (!out) return AEFFT_EINVAL;
     *out = nullptr;
+    flags_from_env_once();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AEFFT_EHIP;
     aefft_ctx* ctx = new aefft_ctx();
@@ -138,6 +165,27 @@ extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
     delete ctx;
 }
 
+// side streams (0: reconstruction inverse FFT, 1: input prefetch) and their events; all-or-nothing
+static int ensure_aux(aefft_ctx* ctx)
+{
+    if (ctx->aux[0]) return AEFFT_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < aefft_ctx::NAUX && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) return AEFFT_OK;
+    for (int i = 0; i < aefft_ctx::NAUX; ++i) {
+        if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+        ctx->aux[i] = nullptr; ctx->ev_join[i] = nullptr;
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    ctx->ev_fork = nullptr;
+    return fail(ctx, AEFFT_EHIP, "side streams", e);
+}
+
 extern "C" const char* aefft_last_error(const aefft_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 static int join_recon(aefft_ctx* ctx)
 {
@@ -147,7 +195,6 @@ static int join_recon(aefft_ctx* ctx)
     return AEFFT_OK;
 }
 extern "C" int aefft_sync(aefft_ctx* ctx) { if (!ctx) return AEFFT_EINVAL; RET_IF(join_recon(ctx)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return AEFFT_OK; }
-extern "C" int aefft_ctx_set_concurrency(aefft_ctx* ctx, int enable) { if (!ctx) return AEFFT_EINVAL; ctx->concurrency = enable != 0; return AEFFT_OK; }
 extern "C" void* aefft_stream(aefft_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" int aefft_prof_enable(aefft_ctx* ctx, int enable)
@@ -234,12 +281,12 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
     return AEFFT_OK;
 }
 
-static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale)
+static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, int ws_id = WS_MID)
 {
     RET_IF(chk_size(ctx, Nx, Ny));
     if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
     void* mid;
-    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * fft_mid_elems(planes, Nx, Nyi / 2), &mid));
+    RET_IF(ws_get(ctx, ws_id, sizeof(float2) * fft_mid_elems(planes, Nx, Nyi / 2), &mid));
     const double b_in = (double)planes * bins(Nxi, Nyi) * 8, b_mid = (double)planes * Nx * (Nyi / 2) * 8, b_out = (double)planes * Nx * Ny * 4;
     hipError_t e;
     {
@@ -387,8 +434,7 @@ static int do_contract(aefft_ctx* ctx, const Contract& q);
 // n independent contractions of class cls (see ContractN) in one launch; falls back to one launch each
 static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, int cls)
 {
-    const char* nogroup = getenv("AEFFT_NOGROUP");
-    if (n <= 8 && n > 1 && !nogroup) {
+    if (n <= 8 && n > 1 && !flag(AEFFT_F_NOGROUP)) {
         ContractN g{};
         double bytes = 0;
         for (int i = 0; i < n; ++i) { g.q[i] = qs[i]; bytes += contract_bytes(qs[i]); }
@@ -872,7 +918,7 @@ static int net_alloc(aefft_net* n, void** p, size_t bytes)
 {
     hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
     if (e != hipSuccess) return fail(n->ctx, AEFFT_ENOMEM, "hipMalloc(net)", e);
-    if (getenv("AEFFT_POISON")) { (void)hipMemset(*p, 0xFF, std::max<size_t>(bytes, 256)); (void)hipDeviceSynchronize(); }
+    if (flag(AEFFT_F_POISON)) { (void)hipMemset(*p, 0xFF, std::max<size_t>(bytes, 256)); (void)hipDeviceSynchronize(); }
     n->allocs.push_back(*p);
     return AEFFT_OK;
 }
@@ -945,6 +991,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         void* dummy;
         // size the context workspaces once so nothing reallocates inside a step
         if ((rc = ws_get(ctx, WS_MID, sizeof(float2) * maxMid, &dummy)) == AEFFT_OK &&
+            (rc = ws_get(ctx, WS_MID3, sizeof(float2) * (size_t)n->B * n->D * n->Nx * (n->Ny / 2), &dummy)) == AEFFT_OK &&
             (rc = ws_get(ctx, WS_DEN, sizeof(float) * maxDen, &dummy)) == AEFFT_OK &&
             (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->real, n->pruned ? 64 : maxReal)) == AEFFT_OK &&
@@ -980,22 +1027,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         e = hipMemsetAsync(q.p, 0, q.dD * 4, ctx->stream); if (e) break;
     }
     if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset weights", e); }
-    if (!ctx->aux[0]) {
-        for (int i = 0; i < aefft_ctx::NAUX; ++i) {
-            // AEFFT_CUMASK=<stride>[,<offset>]: side streams restricted to every <stride>-th CU (experiment: keep the bandwidth-bound
-            // side kernels from flooding the CUs the latency-bound main-stream kernels need)
-            const char* cm = getenv("AEFFT_CUMASK");
-            int stride = 0, offs = 0;
-            if (cm && sscanf(cm, "%d,%d", &stride, &offs) >= 1 && stride > 1) {
-                uint32_t mask[8] = {0};
-                for (int cu = 0; cu < 256; ++cu) if (cu % stride == (offs + i) % stride) mask[cu / 32] |= 1u << (cu % 32);
-                HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->aux[i], 8, mask));
-            } else
-            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
-        }
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    }
+    if (ensure_aux(ctx) != AEFFT_OK) { aefft_net_destroy(n); return AEFFT_EHIP; }
     *out = n;
     return aefft_net_reset_momentum(n);
 }
@@ -1113,7 +1145,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     n->xx_done = false; n->ox_done = 0;
     for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
-    const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !getenv("AEFFT_NOPREFETCH");
+    const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !flag(AEFFT_F_NOPREFETCH);
     if (prefetch) {
         // The caller guarantees the frames are complete: their R2C goes to a side stream and may overlap the tail of the previous
         // step.  It writes the OTHER input-spectra buffer (the current one is still read by that tail), which was last read two
@@ -1122,7 +1154,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         if (n->ev_end_valid[n->step_no & 1]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_end[n->step_no & 1], 0));
         // not earlier than the end of the previous step's gradient half: that is where a data-parallel run waits for its
         // all-reduce (an otherwise idle gap), and what follows on this stream (update, spectra, MSE) is latency-bound
-        if (n->ev_mid_valid && !getenv("AEFFT_PREFETCH_EARLY")) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_mid, 0));
+        if (n->ev_mid_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_mid, 0));
         ctx->cur = ctx->aux[1];
         const int rc = do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID2);
         ctx->cur = ctx->stream;
@@ -1133,10 +1165,9 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     for (int l = 0; l < L; ++l) {
         Pair& q = n->pr[l];
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
-        const char* nofuse = getenv("AEFFT_NOFUSECROP");
-        const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !nofuse;
+        const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !flag(AEFFT_F_NOFUSECROP);
         q.H_stale = false;
-        if (lazy && l == L - 1 && q.G_valid && !getenv("AEFFT_NOGFWD")) {
+        if (lazy && l == L - 1 && q.G_valid && !flag(AEFFT_F_NOGFWD)) {
             // innermost pair of a training step: its hidden layer feeds only its own decoder conv, and the previous step left
             // the collapsed operator of the CURRENT weights behind (G = F.C/(dM dD) in S, DC bias in beta): O = G X + beta below,
             // a quarter of the arithmetic and bytes of conv_k o conv_k, no H.
@@ -1144,7 +1175,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             continue;
         }
         if (fuse && lazy) {
-            const char* nolazy = getenv("AEFFT_NOLAZY");
+            const bool nolazy = flag(AEFFT_F_NOLAZY);
             const Pair& nx = n->pr[l + 1];
             bool done = false;
             if (!nolazy) RET_IF(do_conv_pooled(ctx, q.X, q.C, q.b, nx.X, B, q.dM, q.dD, q.Nx, q.Ny, nx.Nx, nx.Ny, &done));
@@ -1159,7 +1190,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     // decoder (:1356-1361): conv then zero-pad up-sampling.  The up-sampled tensor is never stored: the next
     // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
-    const char* nocompact = getenv("AEFFT_NOCOMPACT");
+    const bool nocompact = flag(AEFFT_F_NOCOMPACT);
     bool compact = lazy && n->compact && !nocompact && L > 1;
     for (int l = L - 1; l >= 0; --l) {
         Pair& q = n->pr[l];
@@ -1175,7 +1206,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
                 // the batch-first gradient term S = -sum_b X X^H needs only the encoder outputs: it shares this launch
                 // (the decoder chain that follows is a sequence of small dependent launches)
                 n->xx_done = false; n->ox_done = 0;
-                if (compact && n->pr[0].P != n->Pc && L + 1 <= 8 && !getenv("AEFFT_NOGROUP")) {
+                if (compact && n->pr[0].P != n->Pc && L + 1 <= 8 && !flag(AEFFT_F_NOGROUP)) {
                     Contract qs[8];
                     qs[0] = k;
                     for (int l2 = 0; l2 < L; ++l2) { Pair& q2 = n->pr[l2]; qs[1 + l2] = mk_XXneg(q2.X, q2.S, B, q2.dD, q2.P); }
@@ -1199,7 +1230,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             k.preDivB = (float)q.dD;
             k.bias = q.p; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
             k.gdNx = q.Nx; k.gdNy = q.Ny; k.gdNxs = n->NxC; k.gdNys = n->NyC; k.gdMask = 1;
-            if (n->xx_done && !getenv("AEFFT_NOGROUP") && !getenv("AEFFT_NOMFMA")) {
+            if (n->xx_done && !flag(AEFFT_F_NOGROUP) && !flag(AEFFT_F_NOMFMA)) {
                 // S = -sum_b X X^H is already out: the support term of the NEXT-inner pair (its decoder output is final) rides along
                 Pair& qi = n->pr[l + 1];
                 Contract qs[2] = {k, qi.O_stale ? mk_OX(qi.Oc, qi.X, qi.S, B, qi.dD, qi.P, n->Pc, qi.Nx, qi.Ny, n->NxC, n->NyC)
@@ -1229,10 +1260,10 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
         Pair& q = n->pr[0];
-        const char* nooverlap = getenv("AEFFT_NOOVERLAP");
+        const bool nooverlap = flag(AEFFT_F_NOOVERLAP);
         const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
         n->recon_deferred = nullptr;
-        if (async && n->input_ready && !getenv("AEFFT_NODEFER")) {
+        if (async && n->input_ready && !flag(AEFFT_F_NODEFER)) {
             // pipelined loop (aefft_net_set_input_ready): launched by aefft_net_step_grad after the gradient half instead
             n->recon_deferred = recon_d;
             n->last_frames = frames_d;
@@ -1246,8 +1277,10 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
             ctx->cur = ctx->aux[0];
         }
-        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon_d, (long)B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny))
-                                 : do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny));
+        // (a side-stream transform has its own column/row workspace: the main stream's FFTs of non-pruned kernel supports use WS_MID)
+        const int wsid = async ? WS_MID3 : WS_MID;
+        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon_d, (long)B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid)
+                                 : do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid);
         ctx->cur = ctx->stream;
         RET_IF(rc);
         n->recon_pending = async;
@@ -1382,25 +1415,6 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     return mark_step_point(n);
 }
 
-// Independent per-pair work is spread over side streams: fork() makes every side stream wait for
-// what is already enqueued on the caller's stream; join() makes the caller's stream wait for them.
-static int fork_streams(aefft_ctx* ctx)
-{
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    for (int i = 0; i < aefft_ctx::NAUX; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
-    return AEFFT_OK;
-}
-static int join_streams(aefft_ctx* ctx)
-{
-    ctx->cur = ctx->stream;
-    for (int i = 0; i < aefft_ctx::NAUX; ++i) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
-    }
-    return AEFFT_OK;
-}
-static bool use_side_streams(const aefft_net* n) { return n->ctx->concurrency && n->pruned && n->L > 1 && n->ctx->aux[0] != nullptr; }
-
 // Step mode runs the same per-pair sequences as pair_grad / pair_apply, phase by phase over ALL pairs, so that
 // the independent contractions of a phase (4 x S, 4 x dc + 4 x df, 4 + 4 re-forward convs) go out as one launch each.
 static int bias_and_kgrad(aefft_net* n, Pair& q)
@@ -1450,13 +1464,13 @@ static int grads_grouped(aefft_net* n)
     }
     n->xx_done = false; n->ox_done = 0;
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
-    const char* nogroup = getenv("AEFFT_NOGROUP");
+    const bool nogroup = flag(AEFFT_F_NOGROUP);
     bool same = n->L > 1 && n->L <= 8 && !nogroup;
     for (int l = 0; l < n->L && same; ++l) {
         const Pair& q = n->pr[l];
         same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
     }
-    const char* noq = getenv("AEFFT_NOQPATH");
+    const bool noq = flag(AEFFT_F_NOQPATH);
     bool qpath = same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
     for (int l = 0; l < n->L && qpath; ++l) qpath = n->pr[l].Q != nullptr;
     if (same) {
@@ -1552,7 +1566,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_i
 {
     if (g_left_in_S) *g_left_in_S = false;
     aefft_ctx* ctx = n->ctx;
-    const char* nofuse = getenv("AEFFT_NOFUSEMSE");
+    const bool nofuse = flag(AEFFT_F_NOFUSEMSE);
     if (!nofuse && q.dD >= 2 && n->B >= 2) {
         RET_IF(do_contract(ctx, mk_G(q.F, q.C, q.G, q.dM, q.dD, q.P)));
         const Contract m = mk_gmse(q.G, q.X, q.F, q.b, q.p, mse_slots, n->B, q.dM, q.dD, q.Nx, q.Ny);
@@ -1565,6 +1579,7 @@ static int reforward_mse(aefft_net* n, Pair& q, float* mse_slots, bool* g_left_i
         if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(mse)", e);
         (void)hipGetLastError();
     }
+    RET_IF(join_recon(ctx));                                                  // a deferred reconstruction may still be reading q.O (== Oc when P == Pc)
     RET_IF(do_conv(ctx, q.X, q.C, q.b, q.H, n->B, q.dM, q.dD, q.Nx, q.Ny));   // :1460
     RET_IF(do_conv(ctx, q.H, q.F, q.p, q.O, n->B, q.dD, q.dM, q.Nx, q.Ny));   // :1461
     return do_diff_mse(ctx, q.X, q.O, nullptr, n->mse_post + (&q - n->pr.data()), nullptr, n->B, q.dM, q.dD, q.Nx, q.Ny);   // :1463
@@ -1574,7 +1589,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
 {
     aefft_ctx* ctx = n->ctx;
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
-    const char* nogroup1 = getenv("AEFFT_NOGROUP");
+    const bool nogroup1 = flag(AEFFT_F_NOGROUP);
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
         const Pair& q = n->pr[l];
@@ -1622,8 +1637,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
     std::vector<char> g_in_S(n->L, 0);       // pair l: S holds G of the updated weights after this call
     {
-        const char* nofuse = getenv("AEFFT_NOFUSEMSE");
-        const char* nogroup = getenv("AEFFT_NOGROUP");
+        const bool nofuse = flag(AEFFT_F_NOFUSEMSE), nogroup = flag(AEFFT_F_NOGROUP);
         Contract gq[8], mq[8];
         int m = 0;
         std::vector<int> rest;
@@ -1640,10 +1654,10 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             // G = F.C/(dM dD).  HBM-sized kernel spectra (no pooling): as the spectrum of the (2Nk-1)^2-tap kernel f (*) c
             // (weight_kernels.hip), which reads the kernels and writes dD*dD planes instead of reading all 2*dM*dD planes of C|F;
             // cache-sized ones: as a per-bin contraction of the spectra (measured faster there).
-            const char* noq = getenv("AEFFT_NOQPATH");
+            const bool noq = flag(AEFFT_F_NOQPATH);
             double cf_bytes = 0;
             for (int l = 0; l < n->L; ++l) cf_bytes += 2.0 * n->pr[l].dM * n->pr[l].dD * n->pr[l].P * 8.0;
-            bool gtaps = !noq && (cf_bytes > 256e6 || getenv("AEFFT_GTAPS")) && m == n->L && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
+            bool gtaps = !noq && (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && m == n->L && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
             for (int l = 0; l < n->L && gtaps; ++l) { const Pair& q = n->pr[l]; gtaps = q.Q && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl; }
             if (gtaps) {
                 GspGroup gg{};
@@ -1736,43 +1750,34 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     aefft_ctx* ctx = n->ctx;
     ++n->step_no;
     RET_IF(net_forward(n, frames_d, recon_d, true));
-    const bool side = use_side_streams(n);
-    if (!side) {
-        RET_IF(grads_grouped(n));
-        if (n->recon_deferred) {
-            // The reconstruction's inverse FFT starts HERE: where a data-parallel run waits for its all-reduce the GPU is otherwise
-            // idle, and what follows on this stream (update, spectra, MSE) is latency-bound.  Joined by aefft_net_step_apply,
-            // aefft_sync or the next call on this net.
-            Pair& q = n->pr[0];
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-            ctx->cur = ctx->aux[0];
-            const int rc = q.O_stale ? do_c2r(ctx, q.Oc, n->recon_deferred, (long)n->B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny))
-                                     : do_c2r(ctx, q.O, n->recon_deferred, (long)n->B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny));
-            ctx->cur = ctx->stream;
-            n->recon_deferred = nullptr;
-            RET_IF(rc);
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-            ctx->recon_join = true;
-        }
-        if (n->recon_pending) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
-            n->recon_pending = false;
-        }
-        n->have_grad = true;
-        if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
-        return mark_step_point(n);
+    {
+        const int rcg = grads_grouped(n);
+        if (rcg != AEFFT_OK) { n->recon_deferred = nullptr; return rcg; }
     }
-    RET_IF(fork_streams(ctx));
-    int rc = AEFFT_OK;
-    for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {     // small (launch-bound) pairs first, the big ones fill in
-        if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
-        rc = pair_grad(n, n->pr[l]);
+    if (n->recon_deferred) {
+        // The reconstruction's inverse FFT starts HERE: where a data-parallel run waits for its all-reduce the GPU is otherwise
+        // idle, and what follows on this stream (update, spectra, MSE) is latency-bound.  Joined by aefft_net_step_apply,
+        // aefft_sync or the next call on this net.
+        Pair& q = n->pr[0];
+        float* recon = n->recon_deferred;
+        n->recon_deferred = nullptr;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+        ctx->cur = ctx->aux[0];
+        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon, (long)n->B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), WS_MID3)
+                                 : do_c2r(ctx, q.O, recon, (long)n->B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), WS_MID3);
+        ctx->cur = ctx->stream;
+        RET_IF(rc);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+        ctx->recon_join = true;
     }
-    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; n->recon_pending = false; }
-    RET_IF(rc);
+    if (n->recon_pending) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+        n->recon_pending = false;
+    }
     n->have_grad = true;
+    if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
     return mark_step_point(n);
 }
 
@@ -1791,22 +1796,7 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     if (!n->have_grad) return fail(ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change (the grouped path re-derives G and sets it again)
     const float del = 0.1f * del0;
-    const bool side = use_side_streams(n) && !maxdiff;        // the multiobjective path shares context workspaces
-    if (!side) {
-        RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
-        n->have_grad = false;
-        RET_IF(join_recon(ctx));
-        return mark_step_point(n);
-    }
-    RET_IF(fork_streams(ctx));
-    int rc = AEFFT_OK;
-    for (int l = n->L - 1; l >= 0 && rc == AEFFT_OK; --l) {
-        if (side) ctx->cur = ctx->aux[l % aefft_ctx::NAUX];
-        rc = pair_apply(n, n->pr[l], del, maxdiff, sym, grad_scale, n->mse_post + l);
-    }
-    if (side) { int r2 = join_streams(ctx); if (rc == AEFFT_OK) rc = r2; }
-    RET_IF(rc);
-    if (mse_d) HIPCHK(ctx, hipMemcpyAsync(mse_d, n->mse_post, sizeof(float) * n->L, hipMemcpyDeviceToDevice, ctx->stream));
+    RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
     n->have_grad = false;
     RET_IF(join_recon(ctx));
     return mark_step_point(n);

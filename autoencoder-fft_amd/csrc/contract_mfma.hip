@@ -407,10 +407,7 @@ hipError_t launch_contract_mfma(ContractN& g, hipStream_t st)
     int trb = 1, tcb = (Cmax >= 8 && !anysplit && !diff) ? 2 : 1;
     // HBM-sized launches (cfg3 without pooling): 8 x 8 tiles halve the operand re-reads that the L2 has to absorb (-10 % step time)
     if (w2 >= 32768 && Rmax >= 8 && Cmax >= 8) { trb = 2; tcb = 2; }
-    const char* tile = getenv("AEFFT_MTILE");              // dev switch: "v,r,c,ks" (read per launch so that a sweep can change it)
-    if (tile) { int v_, r_, c_, k_; if (sscanf(tile, "%d,%d,%d,%d", &v_, &r_, &c_, &k_) == 4) { if (even || v_ == 1) vec = v_; trb = r_; tcb = c_; for (int p = 0; p < g.n; ++p) g.ks[p] = (k_ > 1 && Kmin >= 4) ? 4 : 1; } }
-    const char* xm = getenv("AEFFT_XCDMIN");
-    g.xmin = xm ? atoi(xm) : 64;
+    g.xmin = 64;
 #define AEFFT_MT(V, R_, C_) if (vec == V && trb == R_ && tcb == C_) return diff ? contract_mfma_tile<V, R_, C_, true>(g, st) : contract_mfma_tile<V, R_, C_, false>(g, st);
     AEFFT_MT(2, 1, 1) AEFFT_MT(2, 2, 1) AEFFT_MT(2, 1, 2) AEFFT_MT(2, 2, 2) AEFFT_MT(2, 4, 1) AEFFT_MT(2, 1, 4) AEFFT_MT(2, 4, 2) AEFFT_MT(2, 2, 4)
     AEFFT_MT(1, 1, 1) AEFFT_MT(1, 2, 1) AEFFT_MT(1, 1, 2) AEFFT_MT(1, 2, 2) AEFFT_MT(1, 4, 1) AEFFT_MT(1, 1, 4) AEFFT_MT(1, 4, 2) AEFFT_MT(1, 2, 4) AEFFT_MT(1, 4, 4)

@@ -7,6 +7,11 @@
 
 namespace aefft {
 
+// Development switches (include/aefft.h AEFFT_F_*, aefft_ctx_set_flags): one process-wide word, written by the setter (and once
+// from the AEFFT_FLAGS environment variable when the first context is created), read by the launchers.  No getenv afterwards.
+extern unsigned dev_flags;
+inline bool flag(unsigned f) { return (dev_flags & f) != 0; }
+
 // ---- fft_kernels.hip -------------------------------------------------------------------
 // Twiddle table W[k] = exp(-2*pi*i*k/TW_N), uploaded once per device.
 constexpr int TW_N = 4096;

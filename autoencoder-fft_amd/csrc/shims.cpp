@@ -56,7 +56,7 @@ struct DevBuf {
     explicit DevBuf(size_t count) : n(count)
     {
         hchk(hipMalloc(&d, std::max<size_t>(count, 4) * sizeof(float)), "hipMalloc");
-        if (getenv("AEFFT_POISON")) { hchk(hipMemset(d, 0xFF, std::max<size_t>(count, 4) * sizeof(float)), "poison"); hchk(hipDeviceSynchronize(), "poison"); }
+        if (aefft_ctx_get_flags(nullptr) & AEFFT_F_POISON) { hchk(hipMemset(d, 0xFF, std::max<size_t>(count, 4) * sizeof(float)), "poison"); hchk(hipDeviceSynchronize(), "poison"); }
     }
     ~DevBuf() { if (d) (void)hipFree(d); }
     DevBuf(const DevBuf&) = delete;

@@ -15,6 +15,7 @@
 //                           dB[m] = sum g[m] / Norm ; dP[d] = sum s0[d] / Norm,   s0 = out - in
 //                         with the reference's range tests on every shifted index (lo = 0: '>=0',
 //                         backproplib.cu:209,213; lo = 1: '>0', netlib.cpp:412,416).
+#include "../../include/aefft.h"
 #include "internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -324,7 +325,7 @@ hipError_t launch_conv_spatial(const float* in, float* out, const float* c, cons
 {
     const long total = (long)B * dM * Nx * Ny;
     if (total <= 0) return hipSuccess;
-    if (dconv_ok(Nk, Nl, B) && !getenv("AEFFT_NOTILEDSPATIAL")) {
+    if (dconv_ok(Nk, Nl, B) && !flag(AEFFT_F_NOTILEDSPATIAL)) {
         DConvArgs a{};
         a.in = in; a.w = c; a.bias = b; a.out = out;
         a.Din = dD; a.M = dM; a.Nx = Nx; a.Ny = Ny; a.w_m = dD * Nk * Nl; a.w_d = Nk * Nl;
@@ -454,7 +455,7 @@ hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi
 
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
 {
-    if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !getenv("AEFFT_NOTILEDSPATIAL")) {
+    if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL)) {
         // g = back-convolution of s0 = out - in through f (zero for i' < lo or j' < lo)
         DConvArgs g{};
         g.in = a.out; g.in2 = a.in; g.w = a.f; g.bias = nullptr; g.out = a.ws;

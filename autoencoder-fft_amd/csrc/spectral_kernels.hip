@@ -15,6 +15,7 @@
 //
 // Bins are the fastest dimension everywhere, so a wave reads 64 x 16 B = 1 KiB contiguous per
 // load instruction; each thread owns two bins (one float4) and a TR x TC register tile of outputs.
+#include "../../include/aefft.h"
 #include "internal.h"
 #include <algorithm>
 #include <cstdio>
@@ -500,7 +501,7 @@ template <int VEC, int TR, int TC, int FL, int KS> static hipError_t contract_gr
     return hipGetLastError();
 }
 
-static bool use_mfma() { return !getenv("AEFFT_NOMFMA"); }   // (read per call: the tests switch code paths inside one process)
+static bool use_mfma() { return !flag(AEFFT_F_NOMFMA); }
 
 hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st)
 {
@@ -585,15 +586,13 @@ hipError_t launch_contract2(const Contract2& qq, hipStream_t st)
     // 16-byte loads (VEC = 2) halve the instruction count; TR = 4 only pays when the launch still has >= 4096 waves.
     if (waves(vec, tr, tc) < 4096 && tr == 4) tr = 2;
     if (waves(vec, tr, tc) < 1024 && vec == 2) vec = 1;
-    static const char* tile = getenv("AEFFT_TILE");       // dev switch: "v,r,c"
-    if (tile) { int v_, r_, c_; if (sscanf(tile, "%d,%d,%d", &v_, &r_, &c_) == 3) { if (even || v_ == 1) vec = v_; tr = std::min(r_, tr == 1 ? 1 : (Rmin >= r_ ? r_ : tr)); tc = std::min(c_, Cmin >= c_ ? c_ : tc); } }
-    const char* nofast = getenv("AEFFT_NOFAST");
+    const bool nofast = flag(AEFFT_F_NOFAST);
     const int fc = nofast ? -1 : contract_fast_class(qq);
     if (fc >= 0 && tr >= 2 && tc >= 2) {
         // split-K when even the shrunk tiles leave the chip short of waves and the K chain is long
         int Kmin = 1 << 30;
         for (int p = 0; p < qq.n; ++p) Kmin = std::min(Kmin, qq.q[p].K);
-        static const char* nosplit = getenv("AEFFT_NOSPLITK");
+        const bool nosplit = flag(AEFFT_F_NOSPLITK);
         const bool splitk = !nosplit && Kmin >= 16 && waves(vec, tr, tc) < 4096 && vec * tr * tc <= 16;
 #define AEFFT_CF(V, R_, C_) if (vec == V && tr == R_ && tc == C_) { \
         if (V * R_ * C_ <= 16 && splitk) { \

@@ -138,8 +138,6 @@ def main():
     s = 2 if a.variant == "p2" else 1
     B = a.batch
     net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
-    if a.serial:
-        ctx.set_concurrency(False)
     init_weights(net, np)
     dev = f"cuda:{local}"
     frames = synth_frames(torch, B, D, N, dev, first_index=rank * B)      # each rank its own shard of the global batch
@@ -187,7 +185,7 @@ def main():
     if rank == 0 and not a.no_roofline:
         # per-kernel HIP events on the stream the kernels run on, over the same step
         # (side streams off: overlapped kernels would be charged each other's time)
-        ctx.set_concurrency(False); ctx.prof_enable(True); ctx.prof_reset()
+        ctx.prof_enable(True); ctx.prof_reset()
         for _ in range(3):
             net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
         prof = ctx.prof_read(); ctx.prof_enable(False)

@@ -52,6 +52,32 @@ int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the c
  * context stream (used for per-kernel timing). */
 int aefft_ctx_set_concurrency(aefft_ctx* ctx, int enable);
 void* aefft_stream(aefft_ctx* ctx);             /* the hipStream_t in use */
+/* Development switches: each bit turns ONE optimisation of the training step off (or forces one the shapes would not choose), so
+ * that the parity tests can run every fallback against the oracle.  Process-wide; the default is 0.  The environment variable
+ * AEFFT_FLAGS (comma-separated names without the AEFFT_F_ prefix, e.g. "NOMFMA,NOGROUP") is read ONCE, when the first context is
+ * created; the library never calls getenv after that. */
+enum {
+    AEFFT_F_NOLAZY = 1 << 0,      /* encoder layers on the full grid even when only their pooled part is consumed */
+    AEFFT_F_NOCOMPACT = 1 << 1,   /* decoder outputs on the full grid instead of the support of the up-sampled spectra */
+    AEFFT_F_NOQPATH = 1 << 2,     /* weight gradients through the dc|df spectra instead of the pruned transform Q of S */
+    AEFFT_F_NOFUSEMSE = 1 << 3,   /* post-update MSE by conv, conv, diff instead of the collapsed operator + epilogue */
+    AEFFT_F_NOGROUP = 1 << 4,     /* one launch per pair instead of grouped launches */
+    AEFFT_F_NOMFMA = 1 << 5,      /* scalar-FMA contraction kernels instead of the matrix-core kernel */
+    AEFFT_F_NOGFWD = 1 << 6,      /* innermost pair by conv, conv instead of the collapsed operator left by the previous step */
+    AEFFT_F_NOOVERLAP = 1 << 7,   /* reconstruction inverse FFT on the context stream instead of a side stream */
+    AEFFT_F_NOFUSECROP = 1 << 8,  /* separate resize launches instead of the crop fused into the encoder contraction */
+    AEFFT_F_GTAPS = 1 << 9,       /* force G = spectrum of f (*) c (chosen by itself for HBM-sized spectra) */
+    AEFFT_F_NOPREFETCH = 1 << 10, /* pipelined mode: input R2C on the context stream */
+    AEFFT_F_NODEFER = 1 << 11,    /* pipelined mode: reconstruction not deferred to the end of the gradient half */
+    AEFFT_F_NOTILEDSPATIAL = 1 << 12, /* spatial mode: naive kernels instead of the LDS-tiled / matrix-core ones */
+    AEFFT_F_NOFAST = 1 << 13,     /* generic scalar contraction kernel instead of the lean one */
+    AEFFT_F_NOSPLITK = 1 << 14,   /* no split-K in the scalar contraction */
+    AEFFT_F_POISON = 1 << 15,     /* NaN-fill every allocation (uninitialised reads show up in the tests) */
+    AEFFT_F_NOOPFORM = 1 << 16,   /* training step per frame (batch contractions) instead of the operator form */
+    AEFFT_F_NOGRAPH = 1 << 17     /* training step launched eagerly instead of replayed from captured hipGraphs */
+};
+int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
+unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);
 const char* aefft_version(void);
 
 /* ---- op level: one entry point per reference device routine --------------------------------- */

@@ -28,3 +28,12 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def flags(ctx):
+    """Set the library's development switches (aefft_ctx_set_flags) for one test; the defaults come back afterwards."""
+    def setter(*names):
+        ctx.set_flags(*[n for n in names if n])
+    yield setter
+    ctx.set_flags()

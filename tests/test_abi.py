@@ -38,6 +38,24 @@ def test_python_prototypes_cover_header(built):
     assert sorted(aefft.SIGNATURES) == _declared()
 
 
+def test_flag_table_matches_header():
+    txt = open(os.path.join(ROOT, "include", "aefft.h")).read()
+    hdr = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"AEFFT_F_([A-Z]+)\s*=\s*1\s*<<\s*(\d+)", txt)}
+    assert hdr == aefft.FLAGS and len(hdr) >= 16
+
+
+def test_library_reads_the_environment_once():
+    """development switches live in the context (aefft_ctx_set_flags); the only getenv is AEFFT_FLAGS at context creation"""
+    hits = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "autoencoder-fft_amd", "csrc")):
+        for fn in fns:
+            if fn.endswith((".hip", ".cpp", ".h")):
+                for i, line in enumerate(open(os.path.join(dp, fn), errors="ignore")):
+                    if re.search(r"\bgetenv\s*\(", line):
+                        hits.append((fn, i + 1))
+    assert len(hits) == 1 and hits[0][0] == "aefft_capi.hip", hits
+
+
 def test_no_gpu_fails_loudly(built):
     import torch
     if torch.cuda.is_available():

@@ -126,12 +126,11 @@ def test_config5_full_size_runs(ctx):
     net.close()
 
 
-LITERAL = ["AEFFT_NOLAZY", "AEFFT_NOCOMPACT", "AEFFT_NOQPATH", "AEFFT_NOFUSEMSE", "AEFFT_NOGROUP", "AEFFT_NOMFMA", "AEFFT_NOGFWD",
-           "AEFFT_NOOVERLAP", "AEFFT_NOFUSECROP"]
+LITERAL = ["NOOPFORM", "NOGRAPH", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
 
 
 @pytest.mark.gpu
-def test_optimised_step_equals_literal_sequence_over_three_steps(ctx, monkeypatch):
+def test_optimised_step_equals_literal_sequence_over_three_steps(ctx, flags):
     """Config-2 sized net (256x256, 3 pairs, pool 2), B = 4, three training steps on fresh frames: the default path (matrix
     cores, pooled-grid encoder, support-only decoder, Q-path gradients, collapsed operator, grouped launches) against the
     same library with every one of those switched off, i.e. the literal conv / S / dc,df / C2R / update / R2C / conv, conv /
@@ -142,11 +141,7 @@ def test_optimised_step_equals_literal_sequence_over_three_steps(ctx, monkeypatc
     frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(3)]
     res = []
     for literal in (True, False):
-        for k in LITERAL:
-            if literal:
-                monkeypatch.setenv(k, "1")
-            else:
-                monkeypatch.delenv(k, raising=False)
+        flags(*(LITERAL if literal else []))
         net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
         for l, w in enumerate(ws):
             net.set_pair(l, *w)

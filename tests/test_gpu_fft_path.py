@@ -198,19 +198,18 @@ def test_golden_forward_and_bursts(ctx, tag, D, N, maps, Nk, s):
             net.close()
 
 
-# Every alternative code path of the training step must give the oracle's numbers: the library reads these switches per call.
-STEP_PATHS = ["", "AEFFT_GTAPS", "AEFFT_NOQPATH", "AEFFT_NOCOMPACT", "AEFFT_NOLAZY", "AEFFT_NOGROUP", "AEFFT_NOFUSEMSE",
-              "AEFFT_NOMFMA", "AEFFT_NOOVERLAP", "AEFFT_NOFUSECROP"]
+# Every alternative code path of the training step must give the oracle's numbers (development switches, aefft_ctx_set_flags).
+STEP_PATHS = ["", "NOOPFORM", "NOOPFORM,GTAPS", "NOOPFORM,NOQPATH", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOLAZY", "NOOPFORM,NOGROUP", "NOOPFORM,NOFUSEMSE",
+              "NOOPFORM,NOMFMA", "NOOPFORM,NOOVERLAP", "NOOPFORM,NOFUSECROP", "NOGRAPH", "NOMFMA", "NOGROUP"]
 
 
 @pytest.mark.parametrize("path", STEP_PATHS)
 @pytest.mark.parametrize("B", [1, 3])
-def test_step_equals_oracle_batch_iteration(ctx, B, path, monkeypatch):
+def test_step_equals_oracle_batch_iteration(ctx, B, path, flags):
     """aefft_net_step_grad / step_apply == oracle batch_train_iter for every pair (build-defined
     batch mean); B=1 is the reference loop body.  `path` disables one optimisation
     (or forces one that the small test shapes would not choose) so that its fallback is exercised too."""
-    if path:
-        monkeypatch.setenv(path, "1")
+    flags(*path.split(","))
     _step_vs_oracle(ctx, np.random.default_rng(77 + B), B, 3, 32, 32, [4, 6], 5, 2)
 
 
@@ -271,14 +270,13 @@ def _step_vs_oracle(ctx, rng, B, D, Nx, Ny, maps, Nk, s):
     net.close()
 
 
-@pytest.mark.parametrize("path", ["", "AEFFT_NOGFWD", "AEFFT_NOCOMPACT", "AEFFT_NOMFMA"])
-def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, monkeypatch):
+@pytest.mark.parametrize("path", ["", "NOOPFORM", "NOOPFORM,NOGFWD", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOMFMA", "NOGRAPH"])
+def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, flags):
     """State carried from one training step to the next (the collapsed operator G of the innermost pair, cached spectra,
     stale-layer flags) must be invisible: step 2 on a live net == step 1 of a fresh net that starts from the live net's
     weights and momentum-free... momentum persists across steps, so the comparison is on what does not depend on it:
     the reconstruction, every layer and the packed gradients of step 2."""
-    if path:
-        monkeypatch.setenv(path, "1")
+    flags(*path.split(","))
     rng = np.random.default_rng(123)
     D, N, maps, Nk, s, B = 3, 64, [4, 6, 5], 5, 2, 3
     L = len(maps)

@@ -2,7 +2,7 @@
 """dev tool: host enqueue time vs device time of the cfg3 training step."""
 import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 aefft = importlib.import_module("autoencoder-fft_amd")
 ctx = aefft.Context(0)
 D, N, maps, Nk, B = 3, 512, [8, 16, 32, 64], 5, 32

@@ -2,7 +2,7 @@
 """dev tool: time the spatial-mode kernels (Conv_gpu / backprop_gpu semantics) at the reference's default shape."""
 import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 aefft = importlib.import_module("autoencoder-fft_amd")
 ctx = aefft.Context(0)
 B, dD, dM, N, Nk = int(os.environ.get("B", "32")), 3, int(os.environ.get("M", "50")), int(os.environ.get("N", "256")), int(os.environ.get("NK", "3"))
