@@ -47,10 +47,6 @@ int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, int create_s
 void aefft_ctx_destroy(aefft_ctx* ctx);
 const char* aefft_last_error(const aefft_ctx* ctx);
 int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
-/* The resident network runs the independent per-pair halves of a training step on internal side streams
- * (forked from / joined to the context stream with events).  enable = 0 serialises everything on the
- * context stream (used for per-kernel timing). */
-int aefft_ctx_set_concurrency(aefft_ctx* ctx, int enable);
 void* aefft_stream(aefft_ctx* ctx);             /* the hipStream_t in use */
 /* Development switches: each bit turns ONE optimisation of the training step off (or forces one the shapes would not choose), so
  * that the parity tests can run every fallback against the oracle.  Process-wide; the default is 0.  The environment variable
