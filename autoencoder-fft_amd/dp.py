@@ -44,8 +44,8 @@ def unpack_grads(buf, dims):
 def allreduce_sum_(tensor, group=None):
     """In-place SUM all-reduce of the packed buffer; returns the scale (1/world) the update must apply."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return 1.0
+    if not dist.is_available() or not dist.is_initialized():
+        return 1.0                         # (an initialised group of ONE rank still runs the collective: same code path as N > 1)
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / dist.get_world_size(group)
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s forward+backward of the FFT-mode autoencoder training path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        (N > 1: either launched by torch.distributed.run, one rank per GPU, or -- run plainly -- it starts its N ranks itself)
 
 Workload (BASELINE.json configs[2], SURVEY 8d "config 3"): 512x512 RGB frames, 4 encoder/decoder
 pairs (3->8->16->32->64 maps, 5x5 kernels), FFT mode, 32 synthetic frames per GPU resident in HBM.
@@ -61,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="no side streams (for per-kernel traces)")
+    ap.add_argument("--rccl", action="store_true", help="initialise the nccl (RCCL) process group even at N = 1")
     ap.add_argument("--torch-stream", action="store_true", help="enqueue on torch's current (legacy default) stream instead of a private stream")
     return ap.parse_args()
 
@@ -89,49 +90,79 @@ def init_weights(net, np, rmax=3.0):
         net.set_pair(l, c, rng.uniform(-rmax, rmax, g["dM"]), f, rng.uniform(-rmax, rmax, g["dD"]))
 
 
-def cpu_baseline(np, N, scale):
-    """Pair 1 of this workload (3->8 maps, 5x5) for ONE frame through the reference CPU path:
-    Pool -> Conv -> Conv -> Pool(-s) -> backprop (autoencoder.cpp:135-150,200; netlib.cpp)."""
+def cpu_baseline(N, scale, maps=(8, 16, 32, 64), D=3, Nk=5):
+    """The reference's CPU path (netlib.cpp Pool/Conv/Conv/Pool/backprop; oracle/_ref when built, else the C port) on this
+    host, BASELINE.md section 2: pair 1 of the workload (3->8 maps, 5x5) for ONE frame (i) single-threaded, as the reference
+    runs, and (ii) one frame per core over all host cores; pairs 2-4 are extrapolated from the loop nest's iteration count
+    (dM*dD^2*(Nk*Nl)^2*Nx*Ny for backprop, netlib.cpp:361-451 -- 3.6x, 7.2x, 14.5x pair 1) and labelled as such."""
+    import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu
-    L = cpu.reference() or cpu.port()
-    rng = np.random.default_rng(1)
-    dD, dM, Nk = 3, 8, 5
-    n = N // scale
-    x = np.floor(rng.uniform(0, 256, (dD, N, N))).astype(np.float32)
-    c = rng.uniform(-3, 3, (dM, dD, Nk, Nk)).astype(np.float32); f = rng.uniform(-3, 3, (dD, dM, Nk, Nk)).astype(np.float32)
-    b = rng.uniform(-3, 3, dM).astype(np.float32); p = rng.uniform(-3, 3, dD).astype(np.float32)
-    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)   # the reference prints "mse: ..."
-    try:
-        t0 = time.perf_counter()
-        pin = L.pool(x, (dD, n, n), scale)
-        h = L.conv(pin, c, b)
-        o = L.conv(h, f, p)
-        L.pool(o, (dD, N, N), -scale)
-        L.backprop(pin, o, h, c, b, f, p, 0.2)
-        dt = time.perf_counter() - t0
-    finally:
-        os.dup2(saved, 1); os.close(devnull); os.close(saved)
-    return {"value": 1.0 / dt, "unit": "frames/s (pair 1 of 4 only)", "cores": 1, "kind": L.kind,
-            "sample": f"1 frame {N}x{N}x3, pair 1 only (3->8 maps, 5x5, pool {scale}): Pool+Conv+Conv+Pool+backprop, "
-                      f"{dt:.1f} s single-threaded as the reference runs; pairs 2-4 not timed (O(K^4) nest)"}
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    ctx = mp.get_context("spawn")               # never fork a process that holds a HIP context
+    os.environ["PYTHONPATH"] = os.path.join(ROOT, "oracle") + os.pathsep + os.environ.get("PYTHONPATH", "")   # for the workers
+    job = (N, scale, D, maps[0], Nk, 1)
+    with ctx.Pool(1) as pool:
+        t1, kind = pool.map(cpu.time_pair_frame, [job])[0]
+    with ctx.Pool(cores) as pool:
+        ts = pool.map(cpu.time_pair_frame, [(N, scale, D, maps[0], Nk, 1 + i) for i in range(cores)], chunksize=1)
+    wall = max(t for t, _ in ts)                # the workers run side by side; process start-up is not the reference's cost
+    # iteration counts of the backprop nest per pair (dominant term) relative to pair 1
+    dims, dD, n = [], D, N
+    for dM in maps:
+        n //= scale
+        dims.append(dM * dD * dD * (Nk * Nk) ** 2 * n * n); dD = dM
+    rel = [d / dims[0] for d in dims]
+    full_1t = t1 * sum(rel)
+    return {"value": cores / wall, "unit": "frames/s (pair 1 of 4 only)", "cores": cores, "kind": kind,
+            "sample": f"{cores} frames {N}x{N}x3, one per core, pair 1 only (3->{maps[0]} maps, {Nk}x{Nk}, pool {scale}): "
+                      f"Pool+Conv+Conv+Pool+backprop, {wall:.1f} s (slowest worker)",
+            "single_thread": {"value": 1.0 / t1, "unit": "frames/s (pair 1 of 4 only)", "cores": 1, "seconds_per_frame": t1,
+                              "sample": "1 frame, pair 1 only, single-threaded as the reference runs"},
+            "extrapolated_all_pairs": {"seconds_per_frame_single_thread": full_1t, "frames_per_s_single_thread": 1.0 / full_1t,
+                                       "frames_per_s_all_cores": (cores / wall) / sum(rel), "relative_cost_per_pair": rel,
+                                       "method": "EXTRAPOLATED, not timed: pair-1 time x iteration-count ratio of the backprop loop nest"}}
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a torch.distributed launcher: start the N ranks ourselves (one process per GPU) as a
+    CHILD torch.distributed.run and pass its exit code on.  Nothing in this process has touched the GPU yet
+    (torch.cuda.device_count() does not initialise it), and it never re-execs."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} requested but only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.rccl:
+        # RCCL ("nccl" backend) also at world size 1 when asked: the all-reduce then runs through the same library path
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        assert dist.get_world_size() == world
     aefft = importlib.import_module("autoencoder-fft_amd")
     ctx = aefft.Context(local, use_torch_stream=a.torch_stream)
     N, D, maps, Nk = a.size, 3, [8, 16, 32, 64], 5
@@ -207,12 +238,12 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(np, N, s if s > 1 else 2)
+        cpu = cpu_baseline(N, s if s > 1 else 2)
 
     if rank == 0:
         out = {
             "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": world * B * a.steps / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3-{a.variant.upper()}: {N}x{N}x3 frames, 4 pairs 3->8->16->32->64, 5x5, pool {s}/layer, FFT mode, "
                                    f"fwd + 1 loop-body iteration per pair", "frames_per_gpu": B, "global_batch": world * B,
@@ -224,7 +255,7 @@ def main():
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -89,3 +89,28 @@ def reference():
         else:
             return None
     return _Lib(path, "ref_", "reference")
+
+
+def time_pair_frame(args):
+    """bench.py's cpu_baseline worker (runs in a spawned process, one per core): ONE frame through the CPU path of one
+    encoder/decoder pair -- Pool -> Conv -> Conv -> Pool(-s) -> backprop (autoencoder.cpp:135-150,200) -- returns seconds."""
+    import time
+    N, scale, dD, dM, Nk, seed = args
+    L = reference() or port()
+    rng = np.random.default_rng(seed)
+    n = N // scale
+    x = np.floor(rng.uniform(0, 256, (dD, N, N))).astype(np.float32)
+    c = rng.uniform(-3, 3, (dM, dD, Nk, Nk)).astype(np.float32); f = rng.uniform(-3, 3, (dD, dM, Nk, Nk)).astype(np.float32)
+    b = rng.uniform(-3, 3, dM).astype(np.float32); p = rng.uniform(-3, 3, dD).astype(np.float32)
+    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)   # the reference prints "mse: ..."
+    try:
+        t0 = time.perf_counter()
+        pin = L.pool(x, (dD, n, n), scale)
+        h = L.conv(pin, c, b)
+        o = L.conv(h, f, p)
+        L.pool(o, (dD, N, N), -scale)
+        L.backprop(pin, o, h, c, b, f, p, 0.2)
+        dt = time.perf_counter() - t0
+    finally:
+        os.dup2(saved, 1); os.close(devnull); os.close(saved)
+    return dt, L.kind

@@ -1,0 +1,176 @@
+"""Round-2 GPU parity tests: the headline configuration's training step against the oracle, the default (optimised) path
+against the literal sequence at the bench batch size, geometries that leave the pruned transforms, the pipelined mode's
+reconstruction, and RCCL at world size 1."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import np_ref as R
+from test_gpu_fft_path import _pair, _step_vs_oracle, host, relerr
+
+pytestmark = pytest.mark.gpu
+aefft = importlib.import_module("autoencoder-fft_amd")
+
+LITERAL = ["NOOPFORM", "NOGRAPH", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aefft.Context(0)
+    yield c
+    c.close()
+
+
+def _weights(rng, D, maps, Nk):
+    ws, dD = [], D
+    for dM in maps:
+        _, c, f, b, p = _pair(rng, dD, dM, 8, Nk, 1)
+        ws.append((c, b, f, p)); dD = dM
+    return ws
+
+
+def test_config3_step_vs_oracle(ctx):
+    """BASELINE configs[2] (the bench workload): 512x512, 4 pairs 8/16/32/64 maps, 5x5, pool 2, two DISTINCT frames: one
+    step_grad / step_apply against oracle batch_train_iter -- reconstruction, packed gradients (5e-5), weights, MSE per pair."""
+    _step_vs_oracle(ctx, np.random.default_rng(2026), 2, 3, 512, 512, [8, 16, 32, 64], 5, 2)
+
+
+def test_config3_bench_batch_default_equals_literal(ctx, flags):
+    """The bench's own shape and batch (B = 32): the default path of one training step against the same library with every
+    re-association switched off (per-frame conv / S / dc,df / C2R / update / R2C / conv, conv / MSE on scalar-FMA kernels)."""
+    rng = np.random.default_rng(32)
+    D, N, maps, Nk, s, B = 3, 512, [8, 16, 32, 64], 5, 2, 32
+    ws = _weights(rng, D, maps, Nk)
+    frames = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    res = []
+    for literal in (True, False):
+        flags(*(LITERAL if literal else []))
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        recon, mse = ctx.empty(B, D, N, N), ctx.empty(len(maps))
+        net.step_grad(frames, recon)
+        g = host(net.grad_buffer()).copy()
+        net.step_apply(0.2, 0, 0, 1.0, mse)
+        res.append((g, [net.get_pair(l) for l in range(len(maps))], host(recon).copy(), host(mse).copy()))
+        net.close()
+    (g_lit, w_lit, r_lit, m_lit), (g_opt, w_opt, r_opt, m_opt) = res
+    off = 0
+    for l, (c, b, f, p) in enumerate(ws):                  # per pair: the gradients span many orders of magnitude across pairs
+        n = 2 * c.size + b.size + p.size
+        assert relerr(g_opt[off:off + n], g_lit[off:off + n]) < 5e-5, l
+        off += n
+    for l, (a, b_) in enumerate(zip(w_lit, w_opt)):
+        for x, y, w0 in zip(a, b_, ws[l]):
+            dw = np.abs(x - w0).max()
+            assert np.abs(x - y).max() < 1e-6 + 2e-3 * dw
+    assert relerr(r_opt, r_lit) < 2e-5
+    assert np.allclose(m_lit, m_opt, rtol=1e-4)
+
+
+@pytest.mark.parametrize("D,Nx,Ny,maps,Nk,Nl,s,B", [
+    (3, 32, 32, [4, 6], 5, 3, 2, 2),          # Nk != Nl: no pruned transform, generic C2R/shrink and pad/R2C share WS_MID
+    (2, 16, 1024, [3], 3, 3, 1, 2),           # Ny >= 640: pruned transforms decline
+])
+def test_step_on_non_pruned_geometry_with_reconstruction(ctx, D, Nx, Ny, maps, Nk, Nl, s, B):
+    """with a non-pruned kernel support the backward's generic FFTs used the same column workspace as the
+    reconstruction's inverse FFT on the side stream.  Step parity with recon_d on such shapes."""
+    rng = np.random.default_rng(Nx + Ny + Nk)
+    L = len(maps)
+    xs = np.floor(rng.uniform(0, 256, (B, D, Nx, Ny)))
+    ws, dD = [], D
+    for dM in maps:
+        q = lambda a: a.astype(np.float32).astype(np.float64)
+        ws.append((q(rng.uniform(-1, 1, (dM, dD, Nk, Nl))), q(rng.uniform(-1, 1, dM)), q(rng.uniform(-1, 1, (dD, dM, Nk, Nl))), q(rng.uniform(-1, 1, dD))))
+        dD = dM
+    net = aefft.Net(ctx, D, Nx, Ny, maps, Nk, s, batch=B, Nl=Nl)
+    for l, w in enumerate(ws):
+        net.set_pair(l, *w)
+    net_c = [w[0] for w in ws] + [w[2] for w in ws[::-1]]
+    net_b = [w[1] for w in ws] + [w[3] for w in ws[::-1]]
+    sp = [R.autoenc_fft(xs[i], net_c, net_b, [s] * L + [-s] * L) for i in range(B)]
+    recon = ctx.empty(B, D, Nx, Ny)
+    for rep in range(3):                                      # the race needed timing luck: a few repetitions on fresh buffers
+        recon.fill_(float("nan"))
+        net.step_grad(ctx.dev(xs), recon)
+        gbuf = host(net.grad_buffer()).copy()
+        ctx.sync()
+        for i in range(B):
+            assert relerr(host(recon)[i], sp[i][0][-1]) < 1e-4
+        off = 0
+        for l in range(L):
+            c, b, f, p = ws[l]
+            Xs = [sp[i][2][2 * l + 1] for i in range(B)]; Os = [sp[i][2][4 * L - 1 - 2 * l] for i in range(B)]
+            ref = R.batch_grad(Xs, Xs, Os, sp[0][1][l], sp[0][1][2 * L - 1 - l], b, Nk, Nl)
+            for r in ref:
+                assert relerr(gbuf[off:off + r.size], r.ravel()) < 5e-5
+                off += r.size
+    net.close()
+
+
+@pytest.mark.parametrize("D,N,maps,s,B", [(3, 32, [4, 6], 2, 1), (3, 32, [4], 1, 3), (1, 32, [3, 2], 2, 2)])
+def test_pipelined_mode_reconstruction_equals_stream_ordered(ctx, D, N, maps, s, B):
+    """with aefft_net_set_input_ready the reconstruction is launched on a side stream at the end of the
+    gradient half; the update half must not overwrite what it reads (B = 1 / dD = 1 / s = 1 take the fallbacks that rewrite O)."""
+    rng = np.random.default_rng(N + B + len(maps))
+    ws = _weights(rng, D, maps, 5)
+    frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(3)]
+    out = []
+    for ready in (False, True):
+        net = aefft.Net(ctx, D, N, N, maps, 5, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        net.set_input_ready(ready)
+        recons = []
+        mse = ctx.empty(len(maps))
+        for x in frames:
+            recon = ctx.empty(B, D, N, N); recon.fill_(float("nan"))
+            net.step_grad(x, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+            ctx.sync()
+            recons.append(host(recon).copy())
+        out.append(recons)
+        net.close()
+    for a, b in zip(*out):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+def test_rccl_allreduce_at_world_size_one(ctx):
+    """The nccl (= RCCL) backend and the ExternalStream ordering of dp.DataParallelStep run once on the test box: a group of
+    one rank, the collective enqueued on the library's stream between step_grad and step_apply.  Result == no process group."""
+    import torch
+    import torch.distributed as dist
+    dp = importlib.import_module("autoencoder-fft_amd.dp")
+    rng = np.random.default_rng(11)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6], 5, 2, 4
+    ws = _weights(rng, D, maps, Nk)
+    frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(3)]
+
+    def train():
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        step = dp.DataParallelStep(net)
+        mse = ctx.empty(len(maps))
+        for x in frames:
+            step(x, None, 0.2, 0, 0, mse)
+        ctx.sync()
+        w = [net.get_pair(l) for l in range(len(maps))]
+        net.close()
+        return w
+
+    ref = train()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        got = train()
+        t = torch.ones(4, device="cuda:0")
+        dist.all_reduce(t)
+        assert float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
