@@ -20,7 +20,7 @@ enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
     KID_R2C_ROWS = 0, KID_R2C_COLS, KID_C2R_COLS, KID_C2R_ROWS, KID_CONTRACT, KID_RESIZE, KID_DIFFMSE, KID_BIASGRAD,
-    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_WGRAD, KID_COUNT
+    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_WGRAD, KID_OPFORM, KID_COUNT
 };
 
 struct ProfEvent { hipEvent_t a, b; int kid; double bytes; };
@@ -30,6 +30,7 @@ struct aefft_ctx {
     hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
+    int biasColP1 = 0;               // operator form: conv_k biases go to the affine column of the basis frames only (Contract::biasColP1)
     bool recon_join = false;         // a deferred reconstruction (pipelined mode) still has to be joined from aux[0] (ev_join[0])
     static const int NAUX = 2;
     hipStream_t aux[NAUX] = {};      // side streams: 0 = reconstruction inverse FFT, 1 = input prefetch (created with the first net)
@@ -231,7 +232,7 @@ extern "C" int aefft_prof_reset(aefft_ctx* ctx)
 }
 
 static const char* kid_names[KID_COUNT] = {"r2c_rows", "r2c_cols", "c2r_cols", "c2r_rows", "contract", "resize", "diff_mse",
-                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad", "weight_taps"};
+                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad", "weight_taps", "opform"};
 
 extern "C" int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes)
 {
@@ -313,8 +314,11 @@ static double contract_bytes(const Contract& q)
     return planes * q.P * 8.0;
 }
 
-static int do_contract(aefft_ctx* ctx, const Contract& q)
+static Contract bc(const aefft_ctx* ctx, Contract q) { if (q.bias) q.biasColP1 = ctx->biasColP1; return q; }
+
+static int do_contract(aefft_ctx* ctx, const Contract& q0)
 {
+    const Contract q = bc(ctx, q0);
     const double bytes = contract_bytes(q);
     Bracket br(ctx, KID_CONTRACT, bytes);
     hipError_t e = launch_contract(q, ctx->cur);
@@ -326,7 +330,7 @@ static int do_contract2(aefft_ctx* ctx, const Contract& q0, const Contract& q1)
 {
     const double bytes = contract_bytes(q0) + contract_bytes(q1);
     Contract2 qq{};
-    qq.q[0] = q0; qq.q[1] = q1; qq.n = 2;
+    qq.q[0] = bc(ctx, q0); qq.q[1] = bc(ctx, q1); qq.n = 2;
     Bracket br(ctx, KID_CONTRACT, bytes);
     hipError_t e = launch_contract2(qq, ctx->cur);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "contract2", e);
@@ -437,7 +441,7 @@ static int do_contract_group(aefft_ctx* ctx, const Contract* qs, int n, int nA, 
     if (n <= 8 && n > 1 && !flag(AEFFT_F_NOGROUP)) {
         ContractN g{};
         double bytes = 0;
-        for (int i = 0; i < n; ++i) { g.q[i] = qs[i]; bytes += contract_bytes(qs[i]); }
+        for (int i = 0; i < n; ++i) { g.q[i] = bc(ctx, qs[i]); bytes += contract_bytes(qs[i]); }
         g.n = n; g.nA = nA;
         hipError_t e;
         {
@@ -467,6 +471,7 @@ static int do_conv_pooled(aefft_ctx* ctx, const float2* X, const float2* W, cons
     q.preDivB = (float)R;
     q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
     q.gdNx = Nx; q.gdNy = Ny; q.gdNxs = Nxs; q.gdNys = Nys; q.gdMask = 3;
+    q = bc(ctx, q);
     hipError_t e;
     {
         Bracket br(ctx, KID_CONTRACT, ((double)R * K + (double)K * B + (double)R * B) * Ps * 8.0);
@@ -502,6 +507,7 @@ static int do_conv_up(aefft_ctx* ctx, const float2* Xs, const float2* W, const f
     q.preDivB = (float)R;
     q.bias = bias; q.biasScale = (float)Nx * (float)Ny; q.biasAfterFirst = true;
     q.upNx = Nx; q.upNy = Ny; q.upNxs = sNx; q.upNys = sNy;
+    q = bc(ctx, q);
     // algorithmic bytes: the SMALL input, the weights on the support, the full output
     const double bytes = ((double)K * B * Ps + (double)R * K * Ps + (double)R * B * P) * 8.0;
     Bracket br(ctx, KID_CONTRACT, bytes);
@@ -883,7 +889,13 @@ struct aefft_net {
     int D, Nx, Ny, L, B;
     std::vector<Pair> pr;
     std::vector<void*> allocs;
-    float2* A0 = nullptr;      // R2C of the frames when pair 0 does not pool (then X_0 == A0)
+    // operator form of the training step (opform_kernels.hip)
+    int Bc = 0;                // columns every activation buffer is allocated for: max(B, OPC)
+    float2* Xf = nullptr;      // [B][D][P0] input spectra of the frames (pair 0's X in the per-frame form)
+    float2* A0hat = nullptr;   // [OPC][D][P0] basis frames (pair 0's X in the operator form); null: D > OPC-1
+    float2* Mhat = nullptr;    // [OPC][OPC][P0] second moments of the batch
+    float2* Of = nullptr;      // [B][D][P0] per-frame spectra of the reconstruction (expanded from the operator O^_0)
+    bool op_state = false;     // the activation buffers hold OPERATORS (basis-frame responses) of the last step_grad, not frames
     float* grad = nullptr; size_t grad_n = 0;
     float* scratch = nullptr;  // [mse_pre[L] | mse_post[L] | es of pair 0 (2*dD) | es of pair 1 | ...], zeroed once per step
     size_t scratch_n = 0;
@@ -944,6 +956,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     RET_IF(chk_size(ctx, d->Nx, d->Ny));
     aefft_net* n = new aefft_net();
     n->ctx = ctx; n->D = d->D; n->Nx = d->Nx; n->Ny = d->Ny; n->L = d->npairs; n->B = d->batch;
+    n->Bc = std::max(n->B, (int)OPC);
     n->pr.resize(n->L);
     int dD = d->D, nx = d->Nx, ny = d->Ny;
     size_t maxS = 0, maxBDP = 0, maxW = 0, maxReal = 0, goff = 0, maxMid = 0, maxDen = 0, maxSmall = 0, soff = 2 * (size_t)d->npairs;
@@ -968,7 +981,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         if ((rc = net_alloc_t(n, &q.C, 2 * W))) break;
         q.F = q.C + W;
         q.spectra_valid = false;
-        const size_t BDP = (size_t)n->B * q.dD * q.P, BMP = (size_t)n->B * q.dM * q.P;
+        const size_t BDP = (size_t)n->Bc * q.dD * q.P, BMP = (size_t)n->Bc * q.dM * q.P;
         if (q.s == 1 && l > 0) q.X = n->pr[l - 1].H;
         else if ((rc = net_alloc_t(n, &q.X, BDP))) break;
         if ((rc = net_alloc_t(n, &q.H, BMP)) || (rc = net_alloc_t(n, &q.O, BDP))) break;
@@ -1000,7 +1013,14 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             n->scratch_n = soff; n->mse_pre = n->scratch; n->mse_post = n->scratch + n->L;
             for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
             n->grad_n = goff;
-            if (n->pr[0].s == 1) n->A0 = n->pr[0].X;
+            n->Xf = n->pr[0].X;
+            if (n->D <= OPC - 1) {
+                const Pair& q0 = n->pr[0];
+                if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->A0hat, (size_t)OPC * q0.dD * q0.P);
+                if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Mhat, (size_t)OPC * OPC * q0.P);
+                if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Of, (size_t)n->B * q0.dD * q0.P);
+                if (rc == AEFFT_OK && launch_basis_fill(n->A0hat, q0.dD, q0.P, ctx->stream) != hipSuccess) rc = fail(ctx, AEFFT_EHIP, "basis_fill");
+            }
             // compact decoder outputs (training step): the coarsest pair's grid
             const Pair& qc = n->pr[n->L - 1];
             n->NxC = qc.Nx; n->NyC = qc.Ny; n->Pc = qc.P;
@@ -1008,7 +1028,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
                 Pair& q = n->pr[l];
                 if (rc == AEFFT_OK) rc = net_alloc_t(n, &q.beta, (size_t)q.dD);
                 if (q.P == n->Pc) q.Oc = q.O;            // already on the coarsest grid: nothing to compact
-                else rc = net_alloc_t(n, &q.Oc, (size_t)n->B * q.dD * n->Pc);
+                else rc = net_alloc_t(n, &q.Oc, (size_t)n->Bc * q.dD * n->Pc);
                 if (rc == AEFFT_OK && q.Nk == q.Nl && (q.Nk == 3 || q.Nk == 5)) {
                     const size_t tt = (size_t)(2 * q.Nk - 1) * (2 * q.Nk - 1);
                     rc = net_alloc_t(n, &q.Q, (size_t)q.dD * q.dD * tt);
@@ -1136,11 +1156,45 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
 static int mark_step_point(aefft_net* n);
 // lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
 // discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
-static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool lazy)
+// The training step runs in operator form (opform_kernels.hip) when every pair has the Q-path gradient (equal square 3x3 / 5x5
+// supports with pruned transforms) and the input has at most OPC-1 channels.
+static bool op_eligible(const aefft_net* n)
+{
+    if (flag(AEFFT_F_NOOPFORM) || flag(AEFFT_F_NOQPATH) || !n->A0hat || n->L > 8) return false;
+    const Pair& q0 = n->pr[0];
+    if (q0.Nk != q0.Nl || (q0.Nk != 3 && q0.Nk != 5)) return false;
+    for (const Pair& q : n->pr) if (q.Nk != q0.Nk || q.Nl != q0.Nl || !q.Q || !pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny)) return false;
+    return true;
+}
+
+// the reconstruction's inverse FFT (fft_backproplib.cu:1373) on ctx->cur; operator form: the per-frame spectra are expanded first
+static int launch_recon(aefft_net* n, float* recon_d, int wsid)
+{
+    aefft_ctx* ctx = n->ctx;
+    Pair& q = n->pr[0];
+    const float2* src = q.O_stale ? q.Oc : q.O;
+    const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
+    if (n->op_state) {
+        Bracket br(ctx, KID_OPFORM, ((double)OPC * q.dD + 2.0 * n->B * q.dD) * bins(nxo, nyo) * 8.0);
+        hipError_t e = launch_recon_expand(src, n->Xf, n->Of, n->B, q.dD, q.Nx, q.Ny, nxo, nyo, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "recon_expand", e);
+        src = n->Of;
+    }
+    return do_c2r(ctx, src, recon_d, (long)n->B * q.dD, nxo, nyo, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid);
+}
+
+// op: run the network on the OPC basis frames (the activation buffers then hold the per-bin operators A_l, O^_l) -- the
+// frames themselves only go through the input transform, the second moments and the reconstruction.
+static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool lazy, bool op = false)
 {
     if (!n || !frames_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_forward: bad argument");
     aefft_ctx* ctx = n->ctx;
-    const int B = n->B, L = n->L;
+    const int BF = n->B;                       // frames
+    const int B = op ? (int)OPC : n->B;        // columns of the activation buffers
+    const int L = n->L;
+    struct BiasColGuard { aefft_ctx* c; ~BiasColGuard() { c->biasColP1 = 0; } } guard{ctx};
+    ctx->biasColP1 = op ? (int)OPC : 0;        // conv_k biases: the affine column only
+    n->op_state = op;
     RET_IF(join_recon(ctx));
     n->xx_done = false; n->ox_done = 0;
     for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
@@ -1150,24 +1204,30 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         // The caller guarantees the frames are complete: their R2C goes to a side stream and may overlap the tail of the previous
         // step.  It writes the OTHER input-spectra buffer (the current one is still read by that tail), which was last read two
         // steps ago: wait for that step's end only.
-        std::swap(n->pr[0].X, n->X0alt);
+        std::swap(n->Xf, n->X0alt);
         if (n->ev_end_valid[n->step_no & 1]) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_end[n->step_no & 1], 0));
         // not earlier than the end of the previous step's gradient half: that is where a data-parallel run waits for its
         // all-reduce (an otherwise idle gap), and what follows on this stream (update, spectra, MSE) is latency-bound
         if (n->ev_mid_valid) HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], n->ev_mid, 0));
         ctx->cur = ctx->aux[1];
-        const int rc = do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID2);
+        const int rc = do_r2c(ctx, frames_d, n->Xf, (long)BF * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID2);
         ctx->cur = ctx->stream;
         RET_IF(rc);
         HIPCHK(ctx, hipEventRecord(n->ev_r2c, ctx->aux[1]));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, n->ev_r2c, 0));
-    } else RET_IF(do_r2c(ctx, frames_d, n->pr[0].X, (long)B * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
+    } else RET_IF(do_r2c(ctx, frames_d, n->Xf, (long)BF * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
+    n->pr[0].X = op ? n->A0hat : n->Xf;
+    if (op) {
+        Bracket br(ctx, KID_OPFORM, ((double)BF * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0);
+        hipError_t e = launch_moment(n->Xf, n->Mhat, BF, n->D, n->pr[0].P, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "moment", e);
+    }
     for (int l = 0; l < L; ++l) {
         Pair& q = n->pr[l];
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
         const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !flag(AEFFT_F_NOFUSECROP);
         q.H_stale = false;
-        if (lazy && l == L - 1 && q.G_valid && !flag(AEFFT_F_NOGFWD)) {
+        if (lazy && !op && l == L - 1 && q.G_valid && !flag(AEFFT_F_NOGFWD)) {
             // innermost pair of a training step: its hidden layer feeds only its own decoder conv, and the previous step left
             // the collapsed operator of the CURRENT weights behind (G = F.C/(dM dD) in S, DC bias in beta): O = G X + beta below,
             // a quarter of the arithmetic and bytes of conv_k o conv_k, no H.
@@ -1230,7 +1290,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             k.preDivB = (float)q.dD;
             k.bias = q.p; k.biasScale = (float)q.Nx * (float)q.Ny; k.biasAfterFirst = true;
             k.gdNx = q.Nx; k.gdNy = q.Ny; k.gdNxs = n->NxC; k.gdNys = n->NyC; k.gdMask = 1;
-            if (n->xx_done && !flag(AEFFT_F_NOGROUP) && !flag(AEFFT_F_NOMFMA)) {
+            if (n->xx_done && !op && !flag(AEFFT_F_NOGROUP) && !flag(AEFFT_F_NOMFMA)) {
                 // S = -sum_b X X^H is already out: the support term of the NEXT-inner pair (its decoder output is final) rides along
                 Pair& qi = n->pr[l + 1];
                 Contract qs[2] = {k, qi.O_stale ? mk_OX(qi.Oc, qi.X, qi.S, B, qi.dD, qi.P, n->Pc, qi.Nx, qi.Ny, n->NxC, n->NyC)
@@ -1243,7 +1303,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             hipError_t e;
             {
                 Bracket br(ctx, KID_CONTRACT, ((double)k.R * k.K + (double)k.K * k.C + (double)k.R * k.C) * k.P * 8.0);
-                e = launch_contract(k, ctx->cur);
+                e = launch_contract(bc(ctx, k), ctx->cur);
             }
             if (e == hipSuccess) { q.O_stale = true; continue; }
             if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "contract(compact decoder)", e);
@@ -1259,7 +1319,6 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         RET_IF(do_conv_up(ctx, in.O, q.F, q.p, q.O, B, q.dD, q.dM, q.Nx, q.Ny, in.Nx, in.Ny));
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
-        Pair& q = n->pr[0];
         const bool nooverlap = flag(AEFFT_F_NOOVERLAP);
         const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
         n->recon_deferred = nullptr;
@@ -1278,15 +1337,24 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             ctx->cur = ctx->aux[0];
         }
         // (a side-stream transform has its own column/row workspace: the main stream's FFTs of non-pruned kernel supports use WS_MID)
-        const int wsid = async ? WS_MID3 : WS_MID;
-        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon_d, (long)B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid)
-                                 : do_c2r(ctx, q.O, recon_d, (long)B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid);
+        const int rc = launch_recon(n, recon_d, async ? WS_MID3 : WS_MID);
         ctx->cur = ctx->stream;
         RET_IF(rc);
         n->recon_pending = async;
     }
     n->last_frames = frames_d;
     n->have_forward = true; n->have_grad = false;
+    return AEFFT_OK;
+}
+
+// Layer exports and bursts read per-frame spectra: after a training step in operator form the activation buffers hold operators,
+// so the per-frame forward of the same frames is run first (with the CURRENT weights; the step's gradient state is kept).
+static int ensure_frames(aefft_net* n)
+{
+    if (!n->op_state) return AEFFT_OK;
+    const bool hg = n->have_grad;
+    RET_IF(net_forward(n, n->last_frames, nullptr, false, false));
+    n->have_grad = hg;
     return AEFFT_OK;
 }
 
@@ -1301,6 +1369,7 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     if (!n || layer < 0 || layer > 4 * n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_layer: bad layer index");
     aefft_ctx* ctx = n->ctx;
     RET_IF(join_recon(ctx));
+    if (out_d && n->have_forward) RET_IF(ensure_frames(n));
     const int L = n->L, B = n->B;
     int c, x, y, xi, yi;            // channels, output size, stored spectrum size
     const float2* S = nullptr;
@@ -1382,6 +1451,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     aefft_ctx* ctx = n->ctx;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
     RET_IF(join_recon(ctx));
+    RET_IF(ensure_frames(n));
     Pair& q = n->pr[l];
     RET_IF(ensure_O(n, q));
     if ((size_t)(n_iter + 1) > n->mse_cap) {
@@ -1439,9 +1509,25 @@ static int grads_grouped(aefft_net* n)
 {
     aefft_ctx* ctx = n->ctx;
     Contract qs[8];
+    const bool op = n->op_state;
+    if (op) {
+        // S_l = sum_b (O_b - X_b) X_b^H and the DC error sums of every pair from the operators and the batch moments: one launch
+        SgradGroup sg{};
+        double bytes = 0;
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
+            sg.q[l] = OpPair{q.X, q.O_stale ? q.Oc : q.O, q.S, q.es, q.dD, q.Nx, q.Ny, nxo, nyo, q.P, bins(nxo, nyo)};
+            bytes += ((double)OPC * q.dD * (q.P + bins(nxo, nyo)) + (double)OPC * OPC * q.P + (double)q.dD * q.dD * q.P) * 8.0;
+        }
+        sg.n = n->L; sg.Mhat = n->Mhat; sg.Nx0 = n->pr[0].Nx; sg.Ny0 = n->pr[0].Ny; sg.P0 = n->pr[0].P;
+        Bracket br(ctx, KID_OPFORM, bytes);
+        hipError_t e = launch_sgrad_group(sg, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "sgrad", e);
+    }
     bool comp = false;
     for (int l = 0; l < n->L; ++l) comp = comp || n->pr[l].O_stale;
-    for (int l0 = 0; l0 < n->L; l0 += 4) {
+    for (int l0 = 0; l0 < n->L && !op; l0 += 4) {
         const int m = std::min(4, n->L - l0);
         if (!comp) {
             for (int i = 0; i < m; ++i) { Pair& q = n->pr[l0 + i]; qs[i] = mk_S(q.X, q.X, q.O, q.S, n->B, q.dD, q.P); }
@@ -1465,13 +1551,13 @@ static int grads_grouped(aefft_net* n)
     n->xx_done = false; n->ox_done = 0;
     // DC-bin terms and the pruned inverse transforms of all pairs: one launch each when the pairs share (Nk, Nl)
     const bool nogroup = flag(AEFFT_F_NOGROUP);
-    bool same = n->L > 1 && n->L <= 8 && !nogroup;
+    bool same = op || (n->L > 1 && n->L <= 8 && !nogroup);
     for (int l = 0; l < n->L && same; ++l) {
         const Pair& q = n->pr[l];
         same = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
     }
     const bool noq = flag(AEFFT_F_NOQPATH);
-    bool qpath = same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
+    bool qpath = op || (same && !noq && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5));
     for (int l = 0; l < n->L && qpath; ++l) qpath = n->pr[l].Q != nullptr;
     if (same) {
         BiasGradGroup bg{};
@@ -1485,7 +1571,7 @@ static int grads_grouped(aefft_net* n)
             const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
             const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
             bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, qpath ? nullptr : q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
-                                   (float)q.Nx * (float)q.Ny, Norm, q.O_stale ? n->Pc : q.P, qpath ? q.es : nullptr};
+                                   (float)q.Nx * (float)q.Ny, Norm, q.O_stale ? n->Pc : q.P, qpath ? q.es : nullptr, op ? q.es : nullptr};
             bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
             if (qpath) {
                 // weight gradients through Q = pruned inverse transform of S on the (2Nk-1)^2 offsets (weight_kernels.hip): no dc|df spectra
@@ -1633,6 +1719,28 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
                          q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->mse_post + l));
         RET_IF(pair_spectra(n, q));
     }
+    if (n->op_state) {
+        // post-update MSE (fft_backproplib.cu:1460-1463) in operator form: R = A - F'(C' A / dM + b^) / dD - p^ per bin, then
+        // sum_a R[a] M^ R[a]^H; the updated spectra are read once, nothing is stored (opform_kernels.hip)
+        OpMseGroup og{};
+        double bytes = 0;
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            const float scale = 1.0f / ((float)(2 * q.dM) * (float)q.Nx * (float)q.Ny * (float)n->B) / ((float)q.dD * q.Nx * q.Ny);   // as mk_gmse
+            og.q[l] = OpMsePair{q.X, q.C, q.F, q.b, q.p, n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, q.dD, q.dM, q.Nx, q.Ny, q.P, scale};
+            bytes += (2.0 * q.dM * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
+        }
+        og.n = n->L; og.Mhat = n->Mhat; og.Nx0 = n->pr[0].Nx; og.Ny0 = n->pr[0].Ny; og.P0 = n->pr[0].P;
+        {
+            Bracket br(ctx, KID_OPFORM, bytes);
+            hipError_t e = launch_opmse_group(og, ctx->cur);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "opmse", e);
+        }
+        Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
+        return AEFFT_OK;
+    }
     // post-update MSE (fft_backproplib.cu:1460-1463): G = F.C of every eligible pair in one launch, then every pair's pass
     // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
     std::vector<char> g_in_S(n->L, 0);       // pair l: S holds G of the updated weights after this call
@@ -1749,7 +1857,7 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
     ++n->step_no;
-    RET_IF(net_forward(n, frames_d, recon_d, true));
+    RET_IF(net_forward(n, frames_d, recon_d, true, op_eligible(n)));
     {
         const int rcg = grads_grouped(n);
         if (rcg != AEFFT_OK) { n->recon_deferred = nullptr; return rcg; }
@@ -1758,14 +1866,12 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
         // The reconstruction's inverse FFT starts HERE: where a data-parallel run waits for its all-reduce the GPU is otherwise
         // idle, and what follows on this stream (update, spectra, MSE) is latency-bound.  Joined by aefft_net_step_apply,
         // aefft_sync or the next call on this net.
-        Pair& q = n->pr[0];
         float* recon = n->recon_deferred;
         n->recon_deferred = nullptr;
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
         ctx->cur = ctx->aux[0];
-        const int rc = q.O_stale ? do_c2r(ctx, q.Oc, recon, (long)n->B * q.dD, n->NxC, n->NyC, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), WS_MID3)
-                                 : do_c2r(ctx, q.O, recon, (long)n->B * q.dD, q.Nx, q.Ny, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), WS_MID3);
+        const int rc = launch_recon(n, recon, WS_MID3);
         ctx->cur = ctx->stream;
         RET_IF(rc);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));

@@ -286,7 +286,7 @@ __device__ __forceinline__ void contract_mfma_body(const Contract& q, int bx, in
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     float x = re[v][t][u][i] * bmul, y = (negIm ? -im[v][t][u][i] : im[v][t][u][i]) * bmul;
-                    if (v == 0 && q.bias && grp == 0) x += q.bias[row] * q.biasScale;
+                    if (v == 0 && q.bias && grp == 0 && (q.biasColP1 == 0 || col == q.biasColP1 - 1)) x += q.bias[row] * q.biasScale;
                     of[2 * v] = x * omul; of[2 * v + 1] = y * omul;
                 }
                 V* dst = Op + (row * q.o_r + col * q.o_c) / VEC + ogrp;

@@ -83,7 +83,7 @@ static inline size_t bias_grad_lds(int B, int dD) { return sizeof(float2) * ((si
 __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, const float2* __restrict__ T,
                                                         const float2* __restrict__ F, const float* __restrict__ b,
                                                         float2* __restrict__ df, float* __restrict__ db, float* __restrict__ dp,
-                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO, float* es_out)
+                                                        int B, int dM, int dD, long P, float norm, float Norm, int fix_blocks, int blk, float2* es, long PO, float* es_out, const float* es_in = nullptr)
 {
     // written for 256 threads; in a larger workgroup (the fused kgrad launch) the extra threads only take part in the barriers
     const bool wk = threadIdx.x < 256;
@@ -92,15 +92,19 @@ __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, con
     float* esf = reinterpret_cast<float*>(es);
     float2* val = es + dD;
     // (frame, channel) pairs spread over the threads so the B*dD DC-bin loads are all in flight at once
-    if (wk) for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
-        const float2 o = O[(long)idx * PO], t = T[(long)idx * P];
-        val[idx] = make_float2(o.x - t.x, o.y - t.y);
-    }
-    __syncthreads();
-    if (wk) for (int d = threadIdx.x; d < dD; d += 256) {
-        float sx = 0.f, sy = 0.f;
-        for (int b2 = 0; b2 < B; ++b2) { const float2 v = val[b2 * dD + d]; sx += v.x; sy += v.y; }
-        esf[2 * d] = sx; esf[2 * d + 1] = sy;
+    if (es_in) {                                  // operator form: es comes from sgrad_kernel
+        if (wk) for (int d = threadIdx.x; d < 2 * dD; d += 256) esf[d] = es_in[d];
+    } else {
+        if (wk) for (int idx = threadIdx.x; idx < B * dD; idx += 256) {
+            const float2 o = O[(long)idx * PO], t = T[(long)idx * P];
+            val[idx] = make_float2(o.x - t.x, o.y - t.y);
+        }
+        __syncthreads();
+        if (wk) for (int d = threadIdx.x; d < dD; d += 256) {
+            float sx = 0.f, sy = 0.f;
+            for (int b2 = 0; b2 < B; ++b2) { const float2 v = val[b2 * dD + d]; sx += v.x; sy += v.y; }
+            esf[2 * d] = sx; esf[2 * d + 1] = sy;
+        }
     }
     __syncthreads();
     if (!wk) return;

@@ -45,6 +45,7 @@ struct Contract {
     float postDiv;                      // !=0: the sum is divided by this (gradient_k_io: /Norm, fft.cu:440-441)
     const float* bias; float biasScale; // Re(Out[r][c][0]) += bias[r]*biasScale; null = none
     bool biasAfterFirst;                // true: added right after the k==0 term (fft.cu:183-184); false: after the sum (fft.cu:454)
+    int biasColP1;                      // 0: the bias goes to every column c; k+1: to column k only (operator form: the affine column)
     // Virtual spectral up-sampling of the B operand (fft.cu:117-152 fused into the consumer): B planes
     // are [upNxs][upNys/2+1] spectra that are zero-padded on the fly to the [upNx][upNy/2+1] grid of A/Out.
     // Destination bins outside the padded support only receive the bias term (everything else is 0).
@@ -89,7 +90,8 @@ hipError_t launch_bias_grad(const float2* O, const float2* T, const float2* F, c
                             int B, int dM, int dD, long P, float norm, float Norm, hipStream_t st);
 
 struct BiasGradArgs { const float2 *O, *T, *F; const float* b; float2* df; float *db, *dp; int B, dM, dD; long P; float norm, Norm; long PO; /* plane stride of O (== P unless O is stored on its support only) */
-                      float* es_out; /* nullable: [2*dD] floats, es[d] = sum_b (O_b[d] - T_b[d])(0,0) */ };
+                      float* es_out; /* nullable: [2*dD] floats, es[d] = sum_b (O_b[d] - T_b[d])(0,0) */
+                      const float* es_in; /* nullable: es already known (operator form, sgrad_kernel): O and T are not read */ };
 struct BiasGradGroup { BiasGradArgs a[8]; int n; int start[9], fix[8]; };
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st);
 
@@ -118,6 +120,40 @@ struct GspGroup { GspProb q[8]; int n; int start[9]; };
 hipError_t launch_gspatial_group(GspGroup& g, int Nk, hipStream_t st);
 
 const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()
+
+// ---- opform_kernels.hip ----------------------------------------------------------------
+// Operator form of the training step.  The FFT-mode network is linear (identity activation,
+// backproplib.cu:38-51; conv_k and pool_fft are linear maps), so every per-frame spectrum of a step is an affine function of
+// the frame's own input spectrum x_b (D0 <= 3 channels on pair 0's grid):  X_l,b = A_l [x_b; 1],  O_l,b = O^_l [x_b; 1],
+// with per-bin operators A_l [dD_l x OPC] (column j < D0: response to the unit input on channel j, column OPC-1: response
+// to the zero input = the bias terms).  The operators come out of the ordinary forward run on OPC "basis frames"; the batch
+// enters only through the input transform, the second moments M^[u] = sum_b [x_b;1][x_b;1]^H (OPC x OPC per bin of grid 0)
+// and the reconstruction.  Same sums as gradient_k_io / mse_fft (fft_backproplib.cu:395-498), batch contracted first.
+constexpr int OPC = 4;
+hipError_t launch_basis_fill(float2* A0 /*[OPC][D0][P0]*/, int D0, long P0, hipStream_t st);
+hipError_t launch_moment(const float2* Xf /*[B][D0][P0]*/, float2* Mhat /*[OPC][OPC][P0]*/, int B, int D0, long P0, hipStream_t st);
+struct OpPair {
+    const float2* A;        // A_l    [OPC][dD][P]      (the pair's input on the basis frames)
+    const float2* O;        // O^_l   [OPC][dD][PO]     (its decoder output on the basis frames, stored on the grid [NxO][NyO/2+1])
+    float2* S;              // out:   [dD][dD][P]       S = sum_b (O_b - X_b) X_b^H  (mk_S layout)
+    float* es;              // out:   [2*dD]            es[d] = sum_b (O_b - X_b)[d](0,0)
+    int dD, Nx, Ny, NxO, NyO; long P, PO;
+};
+struct SgradGroup { OpPair q[8]; int n; int start[9]; const float2* Mhat; int Nx0, Ny0; long P0; };
+hipError_t launch_sgrad_group(SgradGroup& g, hipStream_t st);
+// O_0,b = O^_0 [x_b; 1] on the grid O^_0 is stored on: Of [B][D0][PO]
+hipError_t launch_recon_expand(const float2* O0, const float2* Xf, float2* Of, int B, int D0, int Nx0, int Ny0, int NxO, int NyO, hipStream_t st);
+// X_l,b = A_l [x_b; 1] for get_layer-style exports: out [B][dD][P] on the grid [Nx][Ny/2+1] of A
+hipError_t launch_op_expand(const float2* A, const float2* Xf, float2* out, int B, int D0, int dD, int Nx0, int Ny0, int Nx, int Ny, hipStream_t st);
+struct OpMsePair {
+    const float2 *A, *C, *F;   // A_l [OPC][dD][P]; the UPDATED kernel spectra C [dM][dD][P], F [dD][dM][P]
+    const float *b, *p;        // updated biases
+    float* slots;              // MSE_SLOTS accumulators (launch_mse_finish sums them)
+    int dD, dM, Nx, Ny; long P;
+    float scale;               // 1 / (2 dM Nx Ny B) / (dD Nx Ny)
+};
+struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8]; const float2* Mhat; int Nx0, Ny0; long P0; };
+hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st);
 
 // ---- update_kernels.hip ----------------------------------------------------------------
 hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);   // fft.cu:570 (zero-fills)

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, co
 #pragma unroll
         for (int i = 1; i < 8; ++i) if (i < bg.n && blk >= bg.start[i]) p = i;
         const BiasGradArgs& a = bg.a[p];
-        bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, bg.fix[p], blk - bg.start[p], lds, a.PO, a.es_out);
+        bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, bg.fix[p], blk - bg.start[p], lds, a.PO, a.es_out, a.es_in);
         return;
     }
     int p = 0;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
 #pragma unroll
                 for (int i = 0; i < TR; ++i)
 #pragma unroll
-                    for (int j = 0; j < TC; ++j) acc[0][i][j].x += q.bias[rr[i]] * q.biasScale;
+                    for (int j = 0; j < TC; ++j) if (q.biasColP1 == 0 || c0 + j == q.biasColP1 - 1) acc[0][i][j].x += q.bias[rr[i]] * q.biasScale;
             }
         }
     }
@@ -148,7 +148,7 @@ __device__ __forceinline__ void contract_body(const Contract& q, int bx, int by,
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float2 val = acc[v][i][j];
-                if (v == 0 && q.bias && !q.biasAfterFirst && dc_thread) val.x += q.bias[rr[i]] * q.biasScale;
+                if (v == 0 && q.bias && !q.biasAfterFirst && dc_thread && (q.biasColP1 == 0 || c0 + j == q.biasColP1 - 1)) val.x += q.bias[rr[i]] * q.biasScale;
                 of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
             }
             Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
@@ -412,7 +412,7 @@ __device__ __forceinline__ void contract_fast_body(const Contract& q, int bx, in
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float2 val = make_float2(acc[v][i][j].x * bmul, acc[v][i][j].y * bmul);
-                if (v == 0 && q.bias && grp == 0) val.x += q.bias[r0 + i] * q.biasScale;
+                if (v == 0 && q.bias && grp == 0 && (q.biasColP1 == 0 || c0 + j == q.biasColP1 - 1)) val.x += q.bias[r0 + i] * q.biasScale;
                 of[2 * v] = val.x * omul; of[2 * v + 1] = val.y * omul;
             }
             Op[((r0 + i) * q.o_r + (c0 + j) * q.o_c) / VEC + grp] = o;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void bias_grad_group_kernel(const BiasGradGrou
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const BiasGradArgs& a = g.a[p];
-    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es, a.PO, a.es_out);
+    bias_grad_body(a.O, a.T, a.F, a.b, a.df, a.db, a.dp, a.B, a.dM, a.dD, a.P, a.norm, a.Norm, g.fix[p], blockIdx.x - g.start[p], es, a.PO, a.es_out, a.es_in);
 }
 
 hipError_t launch_bias_grad_group(BiasGradGroup& g, hipStream_t st)

@@ -103,7 +103,7 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
         assert np.abs(got_w - w).max() < tol, (n, np.abs(got_w - w).max(), tol, dw)
         assert np.abs(got_b - bias).max() < tol, (n, np.abs(got_b - bias).max(), tol)
     got_out = final[off:].reshape(D, N, N)
-    assert np.abs(got_out - lay_end[-1]).max() < 1e-3 * np.abs(lay_end[-1]).max() + 4.0 * spread_out
+    assert np.abs(got_out - lay_end[-1]).max() < 1e-3 * np.abs(lay_end[-1]).max() + 8.0 * spread_out
 
 
 def test_driver_fails_loudly_without_a_device(tmp_path):
