@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOGRAPH", AEFFT_F_NOGRAPH}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOGRAPH", AEFFT_F_NOGRAPH}, {"NOCHAIN", AEFFT_F_NOCHAIN}};
 static void flags_from_env_once()
 {
     static bool done = false;
@@ -896,6 +896,7 @@ struct aefft_net {
     float2* Mhat = nullptr;    // [OPC][OPC][P0] second moments of the batch
     float2* Of = nullptr;      // [B][D][P0] per-frame spectra of the reconstruction (expanded from the operator O^_0)
     bool op_state = false;     // the activation buffers hold OPERATORS (basis-frame responses) of the last step_grad, not frames
+    int* chain_items = nullptr; int chain_n = 0, chain_main = 0;   // work items of chain_kernel (opform_kernels.hip); chain_main == 0: not served
     float* grad = nullptr; size_t grad_n = 0;
     float* scratch = nullptr;  // [mse_pre[L] | mse_post[L] | es of pair 0 (2*dD) | es of pair 1 | ...], zeroed once per step
     size_t scratch_n = 0;
@@ -935,6 +936,8 @@ static int net_alloc(aefft_net* n, void** p, size_t bytes)
     return AEFFT_OK;
 }
 template <typename T> static int net_alloc_t(aefft_net* n, T** p, size_t count) { return net_alloc(n, reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+static int build_chain_items(aefft_net* n);
 
 extern "C" void aefft_net_destroy(aefft_net* net)
 {
@@ -1020,6 +1023,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
                 if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Mhat, (size_t)OPC * OPC * q0.P);
                 if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Of, (size_t)n->B * q0.dD * q0.P);
                 if (rc == AEFFT_OK && launch_basis_fill(n->A0hat, q0.dD, q0.P, ctx->stream) != hipSuccess) rc = fail(ctx, AEFFT_EHIP, "basis_fill");
+                if (rc == AEFFT_OK) rc = build_chain_items(n);
             }
             // compact decoder outputs (training step): the coarsest pair's grid
             const Pair& qc = n->pr[n->L - 1];
@@ -1156,6 +1160,45 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
 static int mark_step_point(aefft_net* n);
 // lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
 // discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
+// Work items of chain_kernel: for every grid l >= 1 the bins that no bin of grid l+1 maps to (all bins of the coarsest grid).
+// Order: coarsest grid first (dealt so that workgroups w, w+8, ... -- one XCD -- take neighbouring bins and share their 128-byte
+// lines in that XCD's L2), then the middle grids, then the leaves of grid 1 (which the kernel gathers in a tail loop).
+static int build_chain_items(aefft_net* n)
+{
+    const int L = n->L;
+    long deep = n->pr[L - 1].P;
+    bool dims_ok = true;
+    for (const Pair& q : n->pr) dims_ok = dims_ok && q.dD <= 256 && q.dM <= 256;
+    if (!dims_ok || deep > 16384) return AEFFT_OK;                  // large coarsest grids: the layer-by-layer launches stream better
+    auto in_image = [&](int l, long s) {
+        if (l == L - 1) return false;
+        const Pair &a = n->pr[l], &b = n->pr[l + 1];
+        const int nyr = a.Ny / 2 + 1, nyrb = b.Ny / 2 + 1;
+        const int i = (int)(s / nyr), j = (int)(s % nyr);
+        const bool ri = i < b.Nx / 2 || i == a.Nx / 2 || i > a.Nx - b.Nx / 2;
+        const bool cj = j < nyrb - 1 || j == nyr - 1;
+        return ri && cj;
+    };
+    std::vector<int> items;
+    const long per = (deep + 7) / 8;
+    for (long w = 0; w < per * 8; ++w) {
+        const long bin = (w % 8) * per + w / 8;
+        if (bin < deep) { items.push_back(L - 1); items.push_back((int)bin); }
+    }
+    for (int l = L - 2; l >= 2; --l)
+        for (long s2 = 0; s2 < n->pr[l].P; ++s2) if (!in_image(l, s2)) { items.push_back(l); items.push_back((int)s2); }
+    const int n_main = (int)(items.size() / 2);
+    if (L - 1 >= 2)
+        for (long s2 = 0; s2 < n->pr[1].P; ++s2) if (!in_image(1, s2)) { items.push_back(1); items.push_back((int)s2); }
+    if (n_main > 65536) return AEFFT_OK;
+    RET_IF(net_alloc_t(n, &n->chain_items, items.size()));
+    hipError_t e = hipMemcpyAsync(n->chain_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, n->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(n->ctx->stream);
+    if (e != hipSuccess) return fail(n->ctx, AEFFT_EHIP, "chain items", e);
+    n->chain_n = (int)(items.size() / 2); n->chain_main = n_main;
+    return AEFFT_OK;
+}
+
 // The training step runs in operator form (opform_kernels.hip) when every pair has the Q-path gradient (equal square 3x3 / 5x5
 // supports with pruned transforms) and the input has at most OPC-1 channels.
 static bool op_eligible(const aefft_net* n)
@@ -1222,7 +1265,27 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         hipError_t e = launch_moment(n->Xf, n->Mhat, BF, n->D, n->pr[0].P, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "moment", e);
     }
-    for (int l = 0; l < L; ++l) {
+    // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
+    // hidden layers not materialised, decoder outputs on the coarsest grid's support
+    bool chained = false;
+    if (op && lazy && n->chain_main > 0 && (n->compact || L == 1) &&
+        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP))) {
+        ChainArgs ca{};
+        double bytes = 0;
+        for (int l = 0; l < L; ++l) {
+            Pair& q = n->pr[l];
+            ca.lv[l] = ChainLevel{q.C, q.F, q.b, q.p, q.X, q.P != n->Pc ? q.Oc : q.O, q.dD, q.dM, q.Nx, q.Ny, q.P};
+            const double cb = (l + 1 < L) ? (double)n->pr[l + 1].P : (double)q.P;
+            bytes += ((double)q.dM * q.dD * (cb + n->Pc) + (double)OPC * q.dD * (q.P + n->Pc)) * 8.0;
+            q.H_stale = true; q.O_stale = q.P != n->Pc;
+        }
+        ca.L = L; ca.D0 = n->D; ca.items = n->chain_items; ca.n_items = n->chain_n; ca.n_main = n->chain_main; ca.Pc = n->Pc;
+        Bracket br(ctx, KID_OPFORM, bytes);
+        hipError_t e = launch_chain(ca, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
+        chained = true;
+    }
+    for (int l = 0; l < L && !chained; ++l) {
         Pair& q = n->pr[l];
         // the next pair's spectral down-sampling (pool_fft, :1346) is written by this conv's epilogue: no resize launch
         const bool fuse = (l + 1 < L) && n->pr[l + 1].s != 1 && n->fuse_crop && !flag(AEFFT_F_NOFUSECROP);
@@ -1252,7 +1315,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // decoder conv (and the final C2R) read the small spectrum through the zero-pad index map.
     const bool nocompact = flag(AEFFT_F_NOCOMPACT);
     bool compact = lazy && n->compact && !nocompact && L > 1;
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = L - 1; l >= 0 && !chained; --l) {
         Pair& q = n->pr[l];
         q.O_stale = false;
         if (l == L - 1) {

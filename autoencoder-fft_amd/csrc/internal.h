@@ -154,6 +154,15 @@ struct OpMsePair {
 };
 struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8]; const float2* Mhat; int Nx0, Ny0; long P0; };
 hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st);
+// the network on the basis frames in one launch (chain_kernel): per pair the spectra, biases and the operator outputs
+struct ChainLevel { const float2 *C, *F; const float *b, *p; float2 *A /*[OPC][dD][P]*/, *O /*[OPC][dD][Pc]*/; int dD, dM, Nx, Ny; long P; };
+struct ChainArgs {
+    ChainLevel lv[8]; int L, D0;
+    const int* items;          // (level, bin) pairs: bins of grid `level` that no bin of the next grid maps to; the coarsest grid first,
+    int n_items, n_main;       // then the middle grids (n_main items get a workgroup each), then the leaves of grid 1 (gathered in a tail loop)
+    long Pc;
+};
+hipError_t launch_chain(const ChainArgs& g, hipStream_t st);
 
 // ---- update_kernels.hip ----------------------------------------------------------------
 hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);   // fft.cu:570 (zero-fills)

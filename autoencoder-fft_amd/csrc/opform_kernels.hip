@@ -15,18 +15,33 @@
 #include "internal.h"
 #include "device_util.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace aefft {
 
 // bin of the small grid [Nx][Ny/2+1] -> the bin of the big grid [NxB][NyB/2+1] it is cropped from / zero-padded to
 // (pool_fft's index map, fft_backproplib.cu:102-111 and 117-152; compositions of it have the same form)
+// (32-bit arithmetic: a plane has at most 2048 * 1025 bins, and 64-bit division costs hundreds of cycles)
 __device__ __forceinline__ long map_up(long s, int Nx, int Ny, int NxB, int NyB)
 {
-    const int nyr = Ny / 2 + 1, NyrB = NyB / 2 + 1;
-    const int i = (int)(s / nyr), j = (int)(s - (long)i * nyr);
-    const int bi = i < Nx / 2 ? i : (i == Nx / 2 ? NxB / 2 : i + NxB - Nx);
-    const int bj = j < nyr - 1 ? j : NyrB - 1;
-    return (long)bi * NyrB + bj;
+    const unsigned nyr = Ny / 2 + 1, NyrB = NyB / 2 + 1;
+    const unsigned i = (unsigned)s / nyr, j = (unsigned)s - i * nyr;
+    const unsigned bi = i < (unsigned)Nx / 2 ? i : (i == (unsigned)Nx / 2 ? (unsigned)NxB / 2 : i + NxB - Nx);
+    const unsigned bj = j < nyr - 1 ? j : NyrB - 1;
+    return (long)(bi * NyrB + bj);
+}
+// the bin of the small grid [Nxs][Nys/2+1] that lands on bin `bin` of the big grid [Nx][Ny/2+1], or -1 (crop_dest in 32 bits)
+__device__ __forceinline__ int crop_dest32(long bin, int Nx, int Ny, int Nxs, int Nys)
+{
+    const int Nyr = Ny / 2 + 1, Nyrs = Nys / 2 + 1;
+    const int i = (int)((unsigned)bin / (unsigned)Nyr), j = (int)((unsigned)bin - (unsigned)i * Nyr);
+    int di = -1, dj = -1;
+    if (i < Nxs / 2) di = i;
+    else if (i == Nx / 2) di = Nxs / 2;
+    else if (i > Nx - Nxs / 2) di = i - Nx + Nxs;
+    if (j < Nyrs - 1) dj = j;
+    else if (j == Nyr - 1) dj = Nyrs - 1;
+    return (di >= 0 && dj >= 0) ? di * Nyrs + dj : -1;
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -125,45 +140,48 @@ __global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const OpPair& q = g.q[p];
     const int dD = q.dD;
-    const int rgroups = (dD + 3) / 4;
-    const int blk = blockIdx.x - g.start[p];
-    const int bx = blk / rgroups, by = blk - bx * rgroups;
+    const int rgroups = (dD + 3) / 4, bchunks = (dD + 7) / 8;
+    int blk = blockIdx.x - g.start[p];
+    const int bc = blk % bchunks; blk /= bchunks;
+    const int by = blk % rgroups, bx = blk / rgroups;
     const long s = (long)bx * 64 + threadIdx.x;
     const int a = by * 4 + threadIdx.y;
     if (s >= q.P || a >= dD) return;
     const long u = map_up(s, q.Nx, q.Ny, g.Nx0, g.Ny0);
-    const long t = crop_dest(s, q.Nx, q.Ny, q.NxO, q.NyO);                  // the bin of O^'s grid that lands on s, or -1
-    float2 E[OPC];
+    const int t = crop_dest32(s, q.Nx, q.Ny, q.NxO, q.NyO);                 // the bin of O^'s grid that lands on s, or -1
+    // every load of the thread is independent of every other: issue them all, then the arithmetic
+    float2 av[OPC], ov[OPC], Mh[OPC][OPC], ab[8][OPC];
 #pragma unroll
     for (int j = 0; j < OPC; ++j) {
-        const float2 av = q.A[((long)j * dD + a) * q.P + s];
-        float2 ov = make_float2(0.f, 0.f);
-        if (t >= 0) ov = q.O[((long)j * dD + a) * q.PO + t];
-        E[j] = make_float2(ov.x - av.x, ov.y - av.y);
+        av[j] = q.A[((long)j * dD + a) * q.P + s];
+        ov[j] = q.O[((long)j * dD + a) * q.PO + (t >= 0 ? t : 0)];
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) Mh[j][k] = g.Mhat[(long)(j * OPC + k) * g.P0 + u];
     }
+    const int b0 = bc * 8;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+        if (b0 + bb < dD) {                                                   // uniform
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) ab[bb][k] = q.A[((long)k * dD + b0 + bb) * q.P + s];
+        }
     float2 U[OPC];
 #pragma unroll
-    for (int k = 0; k < OPC; ++k) {
+    for (int k = 0; k < OPC; ++k) U[k] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < OPC; ++j) {
+        const float2 E = t >= 0 ? make_float2(ov[j].x - av[j].x, ov[j].y - av[j].y) : make_float2(-av[j].x, -av[j].y);
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) cfma2(U[k], E, Mh[j][k]);
+    }
+    if (s == 0 && bc == 0) { q.es[2 * a] = U[OPC - 1].x; q.es[2 * a + 1] = U[OPC - 1].y; }
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        if (b0 + bb >= dD) break;
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < OPC; ++j) cfma2(acc, E[j], g.Mhat[(long)(j * OPC + k) * g.P0 + u]);
-        U[k] = acc;
-    }
-    if (s == 0) { q.es[2 * a] = U[OPC - 1].x; q.es[2 * a + 1] = U[OPC - 1].y; }
-    for (int b0 = 0; b0 < dD; b0 += 4) {
-        float2 av[4][OPC];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-            for (int k = 0; k < OPC; ++k) av[bb][k] = q.A[((long)k * dD + min(b0 + bb, dD - 1)) * q.P + s];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            if (b0 + bb >= dD) break;
-            float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], av[bb][k]);
-            q.S[((long)a * dD + b0 + bb) * q.P + s] = acc;
-        }
+        for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], ab[bb][k]);
+        q.S[((long)a * dD + b0 + bb) * q.P + s] = acc;
     }
 }
 hipError_t launch_sgrad_group(SgradGroup& g, hipStream_t st)
@@ -172,7 +190,7 @@ hipError_t launch_sgrad_group(SgradGroup& g, hipStream_t st)
     long total = 0;
     for (int i = 0; i < g.n; ++i) {
         g.start[i] = (int)total;
-        total += ((g.q[i].P + 63) / 64) * ((g.q[i].dD + 3) / 4);
+        total += ((g.q[i].P + 63) / 64) * ((g.q[i].dD + 3) / 4) * ((g.q[i].dD + 7) / 8);
     }
     if (total >= (1L << 31)) return hipErrorInvalidValue;
     g.start[g.n] = (int)total;
@@ -249,16 +267,23 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
 #pragma unroll
         for (int k = 0; k < OPC; ++k) t[k] = make_float2(0.f, 0.f);
         const float2* Cp = q.C + (long)m * dD * q.P + sc;
-        for (int d0 = 0; d0 < dD; d0 += 8) {
-            float2 c[8];
+        {
+            auto grp = [&](int d0, auto NU) {
+                constexpr int U = decltype(NU)::value;
+                float2 c[U];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) c[w] = Cp[(long)min(d0 + w, dD - 1) * q.P];
+                for (int w = 0; w < U; ++w) c[w] = Cp[(long)(d0 + w) * q.P];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                if (d0 + w >= dD) break;
+                for (int w = 0; w < U; ++w)
 #pragma unroll
-                for (int k = 0; k < OPC; ++k) cfma2(t[k], c[w], As[(k * dD + d0 + w) * BT + bl]);
-            }
+                    for (int k = 0; k < OPC; ++k) cfma2(t[k], c[w], As[(k * dD + d0 + w) * BT + bl]);
+            };
+            int d0 = 0;
+            for (; d0 + 16 <= dD; d0 += 16) grp(d0, std::integral_constant<int, 16>{});
+            if (d0 + 8 <= dD) { grp(d0, std::integral_constant<int, 8>{}); d0 += 8; }
+            if (d0 + 4 <= dD) { grp(d0, std::integral_constant<int, 4>{}); d0 += 4; }
+            if (d0 + 2 <= dD) { grp(d0, std::integral_constant<int, 2>{}); d0 += 2; }
+            if (d0 < dD) grp(d0, std::integral_constant<int, 1>{});
         }
 #pragma unroll
         for (int k = 0; k < OPC; ++k) { t[k].x *= idM; t[k].y *= idM; }
@@ -275,22 +300,51 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
         for (int i = 0; i < OPC; ++i)
 #pragma unroll
             for (int j = 0; j < OPC; ++j) Mh[i][j] = g.Mhat[(long)(i * OPC + j) * g.P0 + u];
-        for (int a = ry; a < dD; a += RT) {
+        // rows a over the row threads; when there are more row threads than rows, KS of them share a row and split the sum over m
+        int KS = 1;
+        while (KS < 8 && dD * KS * 2 <= RT) KS *= 2;
+        const int ks = ry % KS, ar = ry / KS;
+        float2* Rs = Ts + (size_t)dM * OPC * BT + 8;                      // partial rows of the split: [RT][OPC][BT] (KS > 1 only)
+        for (int a0 = 0; a0 < dD; a0 += RT / KS) {
+            const int a = a0 + ar;
+            const bool act = a < dD;
+            const int ac = act ? a : dD - 1;
             float2 r[OPC];
 #pragma unroll
             for (int k = 0; k < OPC; ++k) r[k] = make_float2(0.f, 0.f);
-            const float2* Fp = q.F + (long)a * dM * q.P + sc;
-            for (int m0 = 0; m0 < dM; m0 += 8) {
-                float2 f[8];
+            const float2* Fp = q.F + (long)ac * dM * q.P + sc;
+            const int mq = (dM + KS - 1) / KS;
+            const int mb = ks * mq, me = min(dM, mb + mq);
+            {
+                auto grp = [&](int m0, auto NU) {
+                    constexpr int U = decltype(NU)::value;
+                    float2 f[U];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) f[w] = Fp[(long)min(m0 + w, dM - 1) * q.P];
+                    for (int w = 0; w < U; ++w) f[w] = Fp[(long)(m0 + w) * q.P];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    if (m0 + w >= dM) break;
+                    for (int w = 0; w < U; ++w)
 #pragma unroll
-                    for (int k = 0; k < OPC; ++k) cfma2(r[k], f[w], Ts[((m0 + w) * OPC + k) * BT + bl]);
-                }
+                        for (int k = 0; k < OPC; ++k) cfma2(r[k], f[w], Ts[((m0 + w) * OPC + k) * BT + bl]);
+                };
+                int m0 = mb;
+                for (; m0 + 16 <= me; m0 += 16) grp(m0, std::integral_constant<int, 16>{});
+                if (m0 + 8 <= me) { grp(m0, std::integral_constant<int, 8>{}); m0 += 8; }
+                if (m0 + 4 <= me) { grp(m0, std::integral_constant<int, 4>{}); m0 += 4; }
+                if (m0 + 2 <= me) { grp(m0, std::integral_constant<int, 2>{}); m0 += 2; }
+                if (m0 < me) grp(m0, std::integral_constant<int, 1>{});
             }
+            if (KS > 1) {                                                // uniform per workgroup
+#pragma unroll
+                for (int k = 0; k < OPC; ++k) Rs[(ry * OPC + k) * BT + bl] = r[k];
+                __syncthreads();
+                if (ks == 0) {
+                    for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+                        for (int k = 0; k < OPC; ++k) { const float2 v = Rs[((ry + k2) * OPC + k) * BT + bl]; r[k].x += v.x; r[k].y += v.y; }
+                }
+                __syncthreads();
+            }
+            if (!act || ks != 0) continue;
 #pragma unroll
             for (int k = 0; k < OPC; ++k) {
                 const float2 av = As[(k * dD + a) * BT + bl];
@@ -307,11 +361,12 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
             }
         }
         const int nyr = q.Ny / 2 + 1;
-        const int j = (int)(sc % nyr);
+        const int j = (int)((unsigned)sc % (unsigned)nyr);
         part *= !ok ? 0.f : ((j > 0 && j < nyr - 1) ? 2.f : 1.f);          // Hermitian half-plane: interior columns count twice
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    __syncthreads();
     float* red = reinterpret_cast<float*>(Ts + (size_t)dM * OPC * BT);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
@@ -323,10 +378,10 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
 
 __global__ __launch_bounds__(256) void opmse_kernel(const OpMseGroup g)
 {
-    extern __shared__ float2 sh[];                                   // As[OPC][dD][BT] | Ts[dM][OPC][BT] | red[4]
-    int p = 0;
+    extern __shared__ float2 sh[];                                   // As[OPC][dD][BT] | Ts[dM][OPC][BT] | red | Rs[256/BT][OPC][BT]
+    int p = g.n - 1;                                                 // pair n-1 owns the first workgroups, pair 0 the last
 #pragma unroll
-    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    for (int i = 6; i >= 0; --i) if (i < g.n - 1 && (int)blockIdx.x >= g.start[i]) p = i;
     const int bt = g.bt[p];                                          // uniform per workgroup
     if (bt == 16) opmse_body<16>(g, p, sh);
     else if (bt == 8) opmse_body<8>(g, p, sh);
@@ -338,12 +393,12 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
     if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
     long total = 0;
     size_t lds = 0;
-    for (int i = 0; i < g.n; ++i) {
+    for (int i = g.n - 1; i >= 0; --i) {                               // innermost (deepest K) pairs first: they are the long poles
         const OpMsePair& q = g.q[i];
         // bins per workgroup: whole 128-byte lines when the pair still yields >= 128 workgroups and its tiles fit 64 KB of LDS
         int bt = 16;
-        while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 60 * 1024)) bt >>= 1;
-        const size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64;
+        while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
+        const size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2);
         if (need > 150 * 1024) return hipErrorInvalidValue;
         g.bt[i] = bt;
         lds = std::max(lds, need);
@@ -351,12 +406,141 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
         total += (q.P + bt - 1) / bt;
     }
     if (total >= (1L << 31)) return hipErrorInvalidValue;
-    g.start[g.n] = (int)total;
+    g.start[g.n] = (int)total;                                         // (start[] is DEscending in i: see opmse_kernel's lookup)
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(opmse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     opmse_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
+    return hipGetLastError();
+}
+
+}  // namespace aefft
+
+namespace aefft {
+
+// ------------------------------------------------------------------------------------------
+// The network on the basis frames in ONE launch (the per-bin operator chain).
+//
+// Every bin is independent: A_l[s] = C_{l-1}[m(s)] A_{l-1}[m(s)] / dM + b^ along the pooling maps, then on the coarsest grid
+// H^ = C_{L-1} A_{L-1} / dM + b^, O^_{L-1} = F_{L-1} H^ / dD + p^, O^_l = F_l[M_l(t)] O^_{l+1} / dD_l + p^_l  (conv_k,
+// fft_backproplib.cu:162-189, on OPC columns; pool_fft's index maps, :87-157).  Work item = one bin of grid l that no bin of
+// grid l+1 maps to (all bins of the coarsest grid): it walks its ancestor chain from grid 0 and stores A_j at each ancestor
+// (every bin of every grid is stored exactly once); items of the coarsest grid continue through the decoder.  One workgroup
+// per item: ALL kernel-spectrum elements the item needs (<= NCH*2048 per round) are requested up front -- 8-byte loads, one
+// 128-byte line per 16 neighbouring items, which the XCD-local L2 serves -- so the chain of small dependent products runs out
+// of LDS behind a single memory round trip instead of one launch (or one round trip) per layer.
+// ------------------------------------------------------------------------------------------
+struct ChainStage { int R, K; float scale, NN; const float* bias; float2* out; long outP, outS; };
+struct ChainChunk { const float2* src; long P; int stage, r0, rows; };
+constexpr int CH_ELEMS = 2048, CH_NCH = 8, CH_MAXSTAGE = 18, CH_MAXCHUNK = 48, CH_VMAX = 256;
+
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
+{
+    __shared__ float2 Ws[CH_ELEMS];
+    __shared__ float2 V[2][CH_VMAX * OPC];
+    __shared__ ChainStage St[CH_MAXSTAGE];
+    __shared__ ChainChunk Ch[CH_MAXCHUNK];
+    __shared__ int nchunk_s;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < g.n_main) {
+        const int lev = g.items[2 * blockIdx.x], s = g.items[2 * blockIdx.x + 1];
+        const bool deep = lev == g.L - 1;
+        if (tid == 0) {
+            long sb[8];
+            sb[lev] = s;
+            for (int j = lev; j > 0; --j) sb[j - 1] = map_up(sb[j], g.lv[j].Nx, g.lv[j].Ny, g.lv[j - 1].Nx, g.lv[j - 1].Ny);
+            int ns = 0, nc = 0;
+            auto add = [&](const float2* W, long P, long bin, int R, int K, float scale, const float* bias, float NN, float2* out, long outP, long outS) {
+                St[ns] = ChainStage{R, K, scale, NN, bias, out, outP, outS};
+                const int rpc = max(1, CH_ELEMS / K);
+                for (int r0 = 0; r0 < R; r0 += rpc) Ch[nc++] = ChainChunk{W + bin, P, ns, r0, min(rpc, R - r0)};
+                ++ns;
+            };
+            for (int j = 1; j <= lev; ++j) {                        // encoder: A_j at the ancestor bin sb[j]
+                const ChainLevel& w = g.lv[j - 1];
+                add(w.C, w.P, sb[j - 1], w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, g.lv[j].A, g.lv[j].P, sb[j]);
+            }
+            if (deep) {
+                const ChainLevel& w = g.lv[lev];
+                add(w.C, w.P, s, w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, nullptr, 0, 0);
+                for (int j = lev; j >= 0; --j) {
+                    const ChainLevel& v = g.lv[j];
+                    add(v.F, v.P, sb[j], v.dD, v.dM, 1.0f / (float)v.dD, v.p, (float)v.Nx * (float)v.Ny, v.O, g.Pc, s);
+                }
+            }
+            nchunk_s = nc;
+        }
+        for (int i = tid; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; V[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+        __syncthreads();
+        const int nchunk = nchunk_s;
+        const bool dc = s == 0;
+        for (int base = 0; base < nchunk; base += CH_NCH) {
+            float2 wreg[CH_NCH][CH_ELEMS / 256];
+#pragma unroll
+            for (int c = 0; c < CH_NCH; ++c) {
+                if (base + c < nchunk) {                              // uniform
+                    const ChainChunk ch = Ch[base + c];
+                    const int K = St[ch.stage].K;
+                    const int ne = ch.rows * K;
+                    const float2* src = ch.src + (long)ch.r0 * K * ch.P;
+#pragma unroll
+                    for (int w = 0; w < CH_ELEMS / 256; ++w) {
+                        const int e = tid + 256 * w;
+                        if (256 * w < ne) wreg[c][w] = src[(long)min(e, ne - 1) * ch.P];      // (uniform test: whole wave-instructions are skipped)
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH_NCH; ++c) {
+                if (base + c < nchunk) {
+                    const ChainChunk ch = Ch[base + c];
+                    const ChainStage st = St[ch.stage];
+                    const int ne = ch.rows * st.K;
+                    __syncthreads();                                  // the previous chunk's readers are done with Ws (and its V writers)
+#pragma unroll
+                    for (int w = 0; w < CH_ELEMS / 256; ++w) { const int e = tid + 256 * w; if (e < ne) Ws[e] = wreg[c][w]; }
+                    __syncthreads();
+                    const float2* Vin = V[ch.stage & 1];
+                    float2* Vout = V[(ch.stage + 1) & 1];
+                    for (int o = tid; o < ch.rows * OPC; o += 256) {
+                        const int rl = o / OPC, col = o - rl * OPC, r = ch.r0 + rl;
+                        float2 acc = make_float2(0.f, 0.f);
+                        const float2* wr = Ws + rl * st.K;
+                        for (int k = 0; k < st.K; ++k) cfma2(acc, wr[k], Vin[k * OPC + col]);
+                        acc.x *= st.scale; acc.y *= st.scale;
+                        if (dc && col == OPC - 1) acc.x += st.bias[r] * st.NN;
+                        Vout[r * OPC + col] = acc;
+                        if (st.out) st.out[((long)col * st.R + r) * st.outP + st.outS] = acc;
+                    }
+                }
+            }
+        }
+    }
+    // tail: bins of grid 1 that no bin of grid 2 maps to -- A_1 is a gather of C_0 (32 threads per bin)
+    if (g.n_items > g.n_main) {
+        const ChainLevel& w0 = g.lv[0];
+        const ChainLevel& w1 = g.lv[1];
+        const float NN = (float)w0.Nx * (float)w0.Ny, sc = 1.0f / (float)w0.dM;
+        for (int it = g.n_main + blockIdx.x * 8 + (tid >> 5); it < g.n_items; it += gridDim.x * 8) {
+            const int s = g.items[2 * it + 1];
+            const long u = map_up(s, w1.Nx, w1.Ny, w0.Nx, w0.Ny);
+            for (int o = tid & 31; o < w0.dM * OPC; o += 32) {
+                const int m = o / OPC, c = o - m * OPC;
+                float2 v = make_float2(0.f, 0.f);
+                if (c < g.D0) { v = w0.C[((long)m * w0.dD + c) * w0.P + u]; v.x *= sc; v.y *= sc; }
+                else if (c == OPC - 1 && s == 0) v.x = w0.b[m] * NN;
+                w1.A[((long)c * w0.dM + m) * w1.P + s] = v;
+            }
+        }
+    }
+}
+
+hipError_t launch_chain(const ChainArgs& g, hipStream_t st)
+{
+    if (g.L < 1 || g.L > 8 || g.n_main < 1) return hipErrorInvalidValue;
+    for (int l = 0; l < g.L; ++l) if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX || g.lv[l].dD > CH_ELEMS || g.lv[l].dM > CH_ELEMS) return hipErrorInvalidValue;
+    chain_kernel<<<dim3((unsigned)g.n_main), 256, 0, st>>>(g);
     return hipGetLastError();
 }
 

@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the short extra runs (cfg3-P1, spatial mode) reported under \"variants\"")
     ap.add_argument("--rccl", action="store_true", help="initialise the nccl (RCCL) process group even at N = 1")
     ap.add_argument("--torch-stream", action="store_true", help="enqueue on torch's current (legacy default) stream instead of a private stream")
     return ap.parse_args()
