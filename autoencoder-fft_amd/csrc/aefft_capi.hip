@@ -896,7 +896,9 @@ struct aefft_net {
     float2* Mhat = nullptr;    // [OPC][OPC][P0] second moments of the batch
     float2* Of = nullptr;      // [B][D][P0] per-frame spectra of the reconstruction (expanded from the operator O^_0)
     bool op_state = false;     // the activation buffers hold OPERATORS (basis-frame responses) of the last step_grad, not frames
-    int* chain_items = nullptr; int chain_n = 0, chain_main = 0;   // work items of chain_kernel (opform_kernels.hip); chain_main == 0: not served
+    float2* Wp = nullptr;      // [Pc][packE] bin-major copy of the kernel spectra the coarsest-grid chain items read (kspec_packed_kernel)
+    PackArgs pack{};           // its description (static per net)
+    bool packed_valid = false; // Wp belongs to the current weights
     float* grad = nullptr; size_t grad_n = 0;
     float* scratch = nullptr;  // [mse_pre[L] | mse_post[L] | es of pair 0 (2*dD) | es of pair 1 | ...], zeroed once per step
     size_t scratch_n = 0;
@@ -1081,7 +1083,7 @@ extern "C" int aefft_net_set_pair(aefft_net* n, int l, const float* c_h, const f
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be pageable / reused by the caller
-    q.spectra_valid = false; q.G_valid = false;
+    q.spectra_valid = false; q.G_valid = false; n->packed_valid = false;
     return AEFFT_OK;
 }
 
@@ -1151,7 +1153,7 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    q.spectra_valid = true; q.G_valid = false;
+    q.spectra_valid = true; q.G_valid = false; n->packed_valid = false;
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.C), q.c, q.dM, q.dD, q.Nk, q.Nl, q.Nx, q.Ny));
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.F), q.f, q.dD, q.dM, q.Nk, q.Nl, q.Nx, q.Ny));
     return AEFFT_OK;
@@ -1160,42 +1162,43 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
 static int mark_step_point(aefft_net* n);
 // lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
 // discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
-// Work items of chain_kernel: for every grid l >= 1 the bins that no bin of grid l+1 maps to (all bins of the coarsest grid).
-// Order: coarsest grid first (dealt so that workgroups w, w+8, ... -- one XCD -- take neighbouring bins and share their 128-byte
-// lines in that XCD's L2), then the middle grids, then the leaves of grid 1 (which the kernel gathers in a tail loop).
+// chain_kernel (opform_kernels.hip) runs the network on the basis frames in one launch; its coarsest-grid workgroups read a
+// bin-major copy of the kernel spectra (kspec_packed_kernel).  Served when the coarsest grid is small (large ones stream better
+// layer by layer) and the channel counts fit the kernel's LDS tiles.
 static int build_chain_items(aefft_net* n)
 {
     const int L = n->L;
-    long deep = n->pr[L - 1].P;
     bool dims_ok = true;
-    for (const Pair& q : n->pr) dims_ok = dims_ok && q.dD <= 256 && q.dM <= 256;
-    if (!dims_ok || deep > 16384) return AEFFT_OK;                  // large coarsest grids: the layer-by-layer launches stream better
-    auto in_image = [&](int l, long s) {
-        if (l == L - 1) return false;
-        const Pair &a = n->pr[l], &b = n->pr[l + 1];
-        const int nyr = a.Ny / 2 + 1, nyrb = b.Ny / 2 + 1;
-        const int i = (int)(s / nyr), j = (int)(s % nyr);
-        const bool ri = i < b.Nx / 2 || i == a.Nx / 2 || i > a.Nx - b.Nx / 2;
-        const bool cj = j < nyrb - 1 || j == nyr - 1;
-        return ri && cj;
-    };
-    std::vector<int> items;
-    const long per = (deep + 7) / 8;
-    for (long w = 0; w < per * 8; ++w) {
-        const long bin = (w % 8) * per + w / 8;
-        if (bin < deep) { items.push_back(L - 1); items.push_back((int)bin); }
+    for (const Pair& q : n->pr) dims_ok = dims_ok && q.dD <= 128 && q.dM <= 128;
+    for (int l = 0; l + 1 < L; ++l) dims_ok = dims_ok && 2 * n->pr[l].dM * (int)OPC * 8 <= 6144;
+    if (!dims_ok || n->pr[L - 1].P > 16384) return AEFFT_OK;
+    // the bin-major copy for the coarsest-grid items: C_0 .. C_{L-1}, F_{L-1} .. F_0 in chain order, segments padded to even sizes
+    bool pk = n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5) && 2 * L <= 16;
+    for (const Pair& q : n->pr) pk = pk && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nk && (((q.dM * q.dD + 1) & ~1) <= 6144);
+    if (pk) {
+        PackArgs& pa = n->pack;
+        int off = 0, ns = 0;
+        for (int l = 0; l < L; ++l) { const Pair& q = n->pr[l]; pa.seg[ns++] = PackSeg{q.c, q.dM * q.dD, l, off}; off += (q.dM * q.dD + 1) & ~1; }
+        for (int l = L - 1; l >= 0; --l) { const Pair& q = n->pr[l]; pa.seg[ns++] = PackSeg{q.f, q.dM * q.dD, l, off}; off += (q.dM * q.dD + 1) & ~1; }
+        pa.nseg = ns; pa.L = L; pa.E = off; pa.Nk = n->pr[0].Nk;
+        for (int l = 0; l < L; ++l) { pa.Nx[l] = n->pr[l].Nx; pa.Ny[l] = n->pr[l].Ny; }
+        pa.NxC = n->pr[L - 1].Nx; pa.NyC = n->pr[L - 1].Ny; pa.Pc = n->pr[L - 1].P; pa.tw = n->ctx->tw;
+        if ((size_t)pa.Pc * pa.E * sizeof(float2) <= (size_t)1 << 30) {
+            RET_IF(net_alloc_t(n, &n->Wp, (size_t)pa.Pc * pa.E));
+            pa.Wp = n->Wp;
+        }
     }
-    for (int l = L - 2; l >= 2; --l)
-        for (long s2 = 0; s2 < n->pr[l].P; ++s2) if (!in_image(l, s2)) { items.push_back(l); items.push_back((int)s2); }
-    const int n_main = (int)(items.size() / 2);
-    if (L - 1 >= 2)
-        for (long s2 = 0; s2 < n->pr[1].P; ++s2) if (!in_image(1, s2)) { items.push_back(1); items.push_back((int)s2); }
-    if (n_main > 65536) return AEFFT_OK;
-    RET_IF(net_alloc_t(n, &n->chain_items, items.size()));
-    hipError_t e = hipMemcpyAsync(n->chain_items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, n->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(n->ctx->stream);
-    if (e != hipSuccess) return fail(n->ctx, AEFFT_EHIP, "chain items", e);
-    n->chain_n = (int)(items.size() / 2); n->chain_main = n_main;
+    return AEFFT_OK;
+}
+
+static int ensure_packed(aefft_net* n)
+{
+    if (!n->Wp || n->packed_valid) return AEFFT_OK;
+    aefft_ctx* ctx = n->ctx;
+    Bracket br(ctx, KID_KSPEC, (double)n->pack.Pc * n->pack.E * 8.0);
+    hipError_t e = launch_kspec_packed(n->pack, ctx->cur);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "kspec_packed", e);
+    n->packed_valid = true;
     return AEFFT_OK;
 }
 
@@ -1268,7 +1271,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
     // hidden layers not materialised, decoder outputs on the coarsest grid's support
     bool chained = false;
-    if (op && lazy && n->chain_main > 0 && (n->compact || L == 1) &&
+    if (op && lazy && n->Wp && (n->compact || L == 1) &&
         !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP))) {
         ChainArgs ca{};
         double bytes = 0;
@@ -1279,7 +1282,8 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
             bytes += ((double)q.dM * q.dD * (cb + n->Pc) + (double)OPC * q.dD * (q.P + n->Pc)) * 8.0;
             q.H_stale = true; q.O_stale = q.P != n->Pc;
         }
-        ca.L = L; ca.D0 = n->D; ca.items = n->chain_items; ca.n_items = n->chain_n; ca.n_main = n->chain_main; ca.Pc = n->Pc;
+        RET_IF(ensure_packed(n));
+        ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
         Bracket br(ctx, KID_OPFORM, bytes);
         hipError_t e = launch_chain(ca, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
@@ -1544,7 +1548,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
         HIPCHK(ctx, hipMemcpyAsync(mse_h, n->mse_dev, sizeof(float) * (n_iter + 1), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    q.G_valid = false;                                  // the burst changed this pair's weights (and used S)
+    q.G_valid = false; n->packed_valid = false;         // the burst changed this pair's weights (and used S)
     return mark_step_point(n);
 }
 
@@ -1738,6 +1742,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
 {
     aefft_ctx* ctx = n->ctx;
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
+    n->packed_valid = false;
     const bool nogroup1 = flag(AEFFT_F_NOGROUP);
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
@@ -1782,6 +1787,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
                          q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->mse_post + l));
         RET_IF(pair_spectra(n, q));
     }
+    if (n->op_state && n->Wp) RET_IF(ensure_packed(n));     // the next step's chain reads the bin-major copy of the NEW weights
     if (n->op_state) {
         // post-update MSE (fft_backproplib.cu:1460-1463) in operator form: R = A - F'(C' A / dM + b^) / dD - p^ per bin, then
         // sum_a R[a] M^ R[a]^H; the updated spectra are read once, nothing is stored (opform_kernels.hip)

@@ -120,6 +120,16 @@ __host__ __device__ constexpr int pad_len(int n) { return n + (n >> 3) + 2; }
 // length N held in LDS at `s` (padded indexing); `t` is this thread's index inside the
 // transform, 0..N/8-1.  Butterfly ib reads elements ib + tt*(N/R) and writes q + S*(R*p + u)
 // with p = ib / S, q = ib % S, twiddle W_n^(p*u), n = N/S.  In place: read, barrier, write, barrier.
+// A transform of N <= 512 points is worked on by N/8 <= 64 threads, i.e. inside ONE wave (callers map transform = tid / T):
+// its LDS reads and writes are issued in program order by that wave and the LDS serves a wave's requests in order, so the
+// exchanges between radix passes need no workgroup barrier -- only a scheduling fence for the compiler.  The waves of a
+// workgroup then run their transforms out of step instead of meeting at 2 barriers per pass.
+template <int N> __device__ __forceinline__ void pass_sync()
+{
+    if constexpr (N / 8 <= 64) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+
 template <int N, int R, int S, int DIR>
 __device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
 {
@@ -133,7 +143,7 @@ __device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
 #pragma unroll
         for (int tt = 0; tt < R; ++tt) a[v * R + tt] = s[pad_idx(ib + tt * (N / R))];
     }
-    __syncthreads();
+    pass_sync<N>();
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const int ib = t + T * v;
@@ -152,7 +162,8 @@ __device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
 #pragma unroll
         for (int u = 0; u < R; ++u) s[pad_idx(q + S * (R * p + u))] = a[v * R + u];
     }
-    __syncthreads();
+    if constexpr (S * R == N) __syncthreads();      // last pass: the result is read across transforms
+    else pass_sync<N>();
 }
 
 template <int N, int S, int DIR> struct Passes {

@@ -158,11 +158,17 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st);
 struct ChainLevel { const float2 *C, *F; const float *b, *p; float2 *A /*[OPC][dD][P]*/, *O /*[OPC][dD][Pc]*/; int dD, dM, Nx, Ny; long P; };
 struct ChainArgs {
     ChainLevel lv[8]; int L, D0;
-    const int* items;          // (level, bin) pairs: bins of grid `level` that no bin of the next grid maps to; the coarsest grid first,
-    int n_items, n_main;       // then the middle grids (n_main items get a workgroup each), then the leaves of grid 1 (gathered in a tail loop)
     long Pc;
+    const float2* Wp; int E;   // bin-major copy of every matrix a coarsest-grid bin needs (kspec_packed_kernel)
+    int tile_start[9];         // (filled by launch_chain) first workgroup of the planar tiles of grid j
+    int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
 };
-hipError_t launch_chain(const ChainArgs& g, hipStream_t st);
+hipError_t launch_chain(ChainArgs& g, hipStream_t st);
+// Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps
+struct PackSeg { const float* k; int n, lev, off; };              // taps [n][Nk*Nk] of one tensor, its pair, its element offset in a record
+struct PackArgs { PackSeg seg[16]; int nseg, L, E, Nk; int Nx[8], Ny[8]; int NxC, NyC; long Pc; float2* Wp; const float2* tw;
+                  unsigned char blk_seg[128]; int blk_start[128]; /* (filled by the launcher) element blocks: tensor, first element */ };
+hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st);
 
 // ---- update_kernels.hip ----------------------------------------------------------------
 hipError_t launch_pad(const float* ck, float* cpad, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st);   // fft.cu:570 (zero-fills)

@@ -426,121 +426,227 @@ namespace aefft {
 // H^ = C_{L-1} A_{L-1} / dM + b^, O^_{L-1} = F_{L-1} H^ / dD + p^, O^_l = F_l[M_l(t)] O^_{l+1} / dD_l + p^_l  (conv_k,
 // fft_backproplib.cu:162-189, on OPC columns; pool_fft's index maps, :87-157).  Work item = one bin of grid l that no bin of
 // grid l+1 maps to (all bins of the coarsest grid): it walks its ancestor chain from grid 0 and stores A_j at each ancestor
-// (every bin of every grid is stored exactly once); items of the coarsest grid continue through the decoder.  One workgroup
-// per item: ALL kernel-spectrum elements the item needs (<= NCH*2048 per round) are requested up front -- 8-byte loads, one
-// 128-byte line per 16 neighbouring items, which the XCD-local L2 serves -- so the chain of small dependent products runs out
-// of LDS behind a single memory round trip instead of one launch (or one round trip) per layer.
+// (every bin of every grid is stored exactly once); items of the coarsest grid continue through the decoder.
+//
+// The kernel spectra are planar ([m][d][bin]): all (m, d) of ONE bin is a gather of 8-byte elements from as many cache lines,
+// and a CU sustains only about one such request per 15 cycles (measured: 3.2 M requests = 87 us chip-wide).  The coarsest-grid
+// items, which need every matrix of every pair (43 KB each at cfg3), therefore read a bin-major copy Wp[t][E] that
+// kspec_packed_kernel evaluates straight from the Nk x Nl taps (a pruned DFT like kspec_kernel, pruned_kernels.hip) whenever the
+// weights change: one coalesced record per item, one memory round trip, the chain of small dependent products then runs out of
+// LDS.  The few middle-grid items (two small matrices each) keep the gather.
 // ------------------------------------------------------------------------------------------
-struct ChainStage { int R, K; float scale, NN; const float* bias; float2* out; long outP, outS; };
-struct ChainChunk { const float2* src; long P; int stage, r0, rows; };
-constexpr int CH_ELEMS = 2048, CH_NCH = 8, CH_MAXSTAGE = 18, CH_MAXCHUNK = 48, CH_VMAX = 256;
+constexpr int CH_VMAX = 128, CH_WL = 6144;
 
+__device__ __forceinline__ float2 phase_tw(const float2* tw, int pos, int off, int N)
+{
+    // e^{-2 pi i pos*off / N}; N a power of two (pruned_kernels.hip `phase`)
+    return tw[((pos * off) & (N - 1)) * (TW_N / N)];
+}
+
+// Wp[t][e]: for support bin t the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 (chain order) at the bins of their grids that t
+// maps to.  Workgroup = 256 consecutive elements x TB support bins; thread = one element: its Nk*Nl taps stay in registers,
+// per bin the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} and then sum_k v_k e^{-2 pi i i kap_k / Nx}
+// (the association of kspec_body).  Stores are coalesced along e.
+template <int NK>
+__global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g)
+{
+    constexpr int TB = 8, KK = NK * NK;
+    __shared__ float2 ph[TB][2][NK];                               // [bin][row/col][tap] phases on this tensor's grid
+    __shared__ float taps[256 * KK];                               // the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
+    const PackSeg sd = g.seg[g.blk_seg[blockIdx.x]];               // (uniform: a workgroup's elements belong to ONE tensor)
+    const int l0 = g.blk_start[blockIdx.x];                        // first element of the block inside the tensor
+    const int nel = min(256, sd.n - l0);
+    const int t0 = blockIdx.y * TB;
+    for (int i = threadIdx.x; i < TB * 2 * NK; i += 256) {
+        const int k = i % NK, rc = (i / NK) & 1, b = i / (2 * NK);
+        const int t = min(t0 + b, (int)g.Pc - 1);
+        const long s = map_up(t, g.NxC, g.NyC, g.Nx[sd.lev], g.Ny[sd.lev]);
+        const int nyr = g.Ny[sd.lev] / 2 + 1;
+        const int bi = (int)((unsigned)s / (unsigned)nyr), bj = (int)((unsigned)s - (unsigned)bi * nyr);
+        ph[b][rc][k] = rc == 0 ? phase_tw(g.tw, bi, k - NK / 2, g.Nx[sd.lev]) : phase_tw(g.tw, bj, k - NK / 2, g.Ny[sd.lev]);
+    }
+    {
+        const float* src = sd.k + (long)l0 * KK;                   // nel * KK consecutive floats
+        const int nf = nel * KK;
+        float v[KK];                                               // every load of the copy in flight at once: one round trip
+#pragma unroll
+        for (int w = 0; w < KK; ++w) v[w] = src[min(w * 256 + (int)threadIdx.x, nf - 1)];
+#pragma unroll
+        for (int w = 0; w < KK; ++w) { const int f = w * 256 + threadIdx.x; if (f < nf) taps[f] = v[w]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nel) return;
+    const int e = sd.off + l0 + threadIdx.x;
+    float c[NK * NK];
+#pragma unroll
+    for (int i = 0; i < NK * NK; ++i) c[i] = taps[threadIdx.x * KK + i];
+    for (int b = 0; b < TB && t0 + b < g.Pc; ++b) {
+        float2 cp[NK], rp[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { rp[k] = ph[b][0][k]; cp[k] = ph[b][1][k]; }
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < NK; ++l) { v.x += c[k * NK + l] * cp[l].x; v.y += c[k * NK + l] * cp[l].y; }
+            acc.x += v.x * rp[k].x - v.y * rp[k].y;
+            acc.y += v.x * rp[k].y + v.y * rp[k].x;
+        }
+        g.Wp[(long)(t0 + b) * g.E + e] = acc;
+    }
+}
+
+hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
+{
+    if (g.nseg < 1 || g.nseg > 16 || g.L < 1 || g.L > 8 || g.E < 1 || (g.Nk != 3 && g.Nk != 5)) return hipErrorInvalidValue;
+    int nb = 0;
+    for (int i = 0; i < g.nseg; ++i)
+        for (int l0 = 0; l0 < g.seg[i].n; l0 += 256) { if (nb >= 128) return hipErrorInvalidValue; g.blk_seg[nb] = i; g.blk_start[nb] = l0; ++nb; }
+    const dim3 grid((unsigned)nb, (unsigned)((g.Pc + 7) / 8));
+    if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, 0, st>>>(g);
+    else kspec_packed_kernel<5><<<grid, 256, 0, st>>>(g);
+    return hipGetLastError();
+}
+
+// out[r][c] = scale * sum_k W[r][k] V[k][c] (+ bias[r] NN on the affine column at the DC bin); W = a row-major matrix of the
+// item's packed record, read straight from global memory (contiguous rows, L2-resident), V in LDS.  Thread = one output.
+__device__ __forceinline__ void chain_stage_rec(const float2* __restrict__ Ws, const float2* __restrict__ Vin, float2* __restrict__ Vout,
+                                                int R, int K, float scale, const float* __restrict__ bias, float NN, bool dc,
+                                                float2* __restrict__ out, long outP, long outS)
+{
+    for (int o = threadIdx.x; o < R * OPC; o += 256) {
+        const int r = o / OPC, col = o - r * OPC;
+        float2 acc = make_float2(0.f, 0.f);
+        const float2* wr = Ws + r * K;
+        // the row (K contiguous elements of the record) in groups of 16 loads: all in flight before the first use
+        auto grp = [&](int k0, auto NU) {
+            constexpr int U = decltype(NU)::value;
+            float2 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = wr[k0 + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cfma2(acc, w[u], Vin[(k0 + u) * OPC + col]);
+        };
+        int k0 = 0;
+        for (; k0 + 16 <= K; k0 += 16) grp(k0, std::integral_constant<int, 16>{});
+        if (k0 + 8 <= K) { grp(k0, std::integral_constant<int, 8>{}); k0 += 8; }
+        if (k0 + 4 <= K) { grp(k0, std::integral_constant<int, 4>{}); k0 += 4; }
+        if (k0 + 2 <= K) { grp(k0, std::integral_constant<int, 2>{}); k0 += 2; }
+        if (k0 < K) grp(k0, std::integral_constant<int, 1>{});
+        acc.x *= scale; acc.y *= scale;
+        if (dc && col == OPC - 1) acc.x += bias[r] * NN;
+        Vout[r * OPC + col] = acc;
+        if (out) out[((long)col * R + r) * outP + outS] = acc;
+    }
+}
+
+// One launch, two kinds of workgroups, all independent:
+//  * blockIdx < Pc: the coarsest-grid bin t.  A_1 .. A_{L-1}, H^ and O^_{L-1} .. O^_0 of that bin, every matrix read from the
+//    bin's packed record (contiguous rows); only the running OPC-column vector lives in LDS, so many workgroups share a CU
+//    and hide each other's stage-to-stage latency.  The decoder outputs are stored.
+//  * the rest: a tile of CH_BT consecutive bins of grid j (1 <= j < L), threads = (bin, row group).  It recomputes the tile's
+//    ancestor chain A_1 .. A_j from the PLANAR spectra (small matrices; lanes along the bins: coalesced) and stores A_j.
+// No workgroup waits for another one; the only cost of the independence is the re-evaluation of a few small products.
+constexpr int CH_BT = 8;
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
 {
-    __shared__ float2 Ws[CH_ELEMS];
-    __shared__ float2 V[2][CH_VMAX * OPC];
-    __shared__ ChainStage St[CH_MAXSTAGE];
-    __shared__ ChainChunk Ch[CH_MAXCHUNK];
-    __shared__ int nchunk_s;
+    extern __shared__ float2 Wl[];                                   // planar tiles: two V tiles [rows][OPC][CH_BT]
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < g.n_main) {
-        const int lev = g.items[2 * blockIdx.x], s = g.items[2 * blockIdx.x + 1];
-        const bool deep = lev == g.L - 1;
-        if (tid == 0) {
-            long sb[8];
-            sb[lev] = s;
-            for (int j = lev; j > 0; --j) sb[j - 1] = map_up(sb[j], g.lv[j].Nx, g.lv[j].Ny, g.lv[j - 1].Nx, g.lv[j - 1].Ny);
-            int ns = 0, nc = 0;
-            auto add = [&](const float2* W, long P, long bin, int R, int K, float scale, const float* bias, float NN, float2* out, long outP, long outS) {
-                St[ns] = ChainStage{R, K, scale, NN, bias, out, outP, outS};
-                const int rpc = max(1, CH_ELEMS / K);
-                for (int r0 = 0; r0 < R; r0 += rpc) Ch[nc++] = ChainChunk{W + bin, P, ns, r0, min(rpc, R - r0)};
-                ++ns;
-            };
-            for (int j = 1; j <= lev; ++j) {                        // encoder: A_j at the ancestor bin sb[j]
-                const ChainLevel& w = g.lv[j - 1];
-                add(w.C, w.P, sb[j - 1], w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, g.lv[j].A, g.lv[j].P, sb[j]);
-            }
-            if (deep) {
-                const ChainLevel& w = g.lv[lev];
-                add(w.C, w.P, s, w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, nullptr, 0, 0);
-                for (int j = lev; j >= 0; --j) {
-                    const ChainLevel& v = g.lv[j];
-                    add(v.F, v.P, sb[j], v.dD, v.dM, 1.0f / (float)v.dD, v.p, (float)v.Nx * (float)v.Ny, v.O, g.Pc, s);
-                }
-            }
-            nchunk_s = nc;
-        }
+    const int L = g.L;
+    if ((long)blockIdx.x < g.Pc) {
+        __shared__ float2 V[2][CH_VMAX * OPC];
+        const int t = blockIdx.x;
+        const bool dc = t == 0;
+        const float2* rec = g.Wp + (long)t * g.E;
         for (int i = tid; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; V[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
-        __syncthreads();
-        const int nchunk = nchunk_s;
-        const bool dc = s == 0;
-        for (int base = 0; base < nchunk; base += CH_NCH) {
-            float2 wreg[CH_NCH][CH_ELEMS / 256];
-#pragma unroll
-            for (int c = 0; c < CH_NCH; ++c) {
-                if (base + c < nchunk) {                              // uniform
-                    const ChainChunk ch = Ch[base + c];
-                    const int K = St[ch.stage].K;
-                    const int ne = ch.rows * K;
-                    const float2* src = ch.src + (long)ch.r0 * K * ch.P;
-#pragma unroll
-                    for (int w = 0; w < CH_ELEMS / 256; ++w) {
-                        const int e = tid + 256 * w;
-                        if (256 * w < ne) wreg[c][w] = src[(long)min(e, ne - 1) * ch.P];      // (uniform test: whole wave-instructions are skipped)
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CH_NCH; ++c) {
-                if (base + c < nchunk) {
-                    const ChainChunk ch = Ch[base + c];
-                    const ChainStage st = St[ch.stage];
-                    const int ne = ch.rows * st.K;
-                    __syncthreads();                                  // the previous chunk's readers are done with Ws (and its V writers)
-#pragma unroll
-                    for (int w = 0; w < CH_ELEMS / 256; ++w) { const int e = tid + 256 * w; if (e < ne) Ws[e] = wreg[c][w]; }
-                    __syncthreads();
-                    const float2* Vin = V[ch.stage & 1];
-                    float2* Vout = V[(ch.stage + 1) & 1];
-                    for (int o = tid; o < ch.rows * OPC; o += 256) {
-                        const int rl = o / OPC, col = o - rl * OPC, r = ch.r0 + rl;
-                        float2 acc = make_float2(0.f, 0.f);
-                        const float2* wr = Ws + rl * st.K;
-                        for (int k = 0; k < st.K; ++k) cfma2(acc, wr[k], Vin[k * OPC + col]);
-                        acc.x *= st.scale; acc.y *= st.scale;
-                        if (dc && col == OPC - 1) acc.x += st.bias[r] * st.NN;
-                        Vout[r * OPC + col] = acc;
-                        if (st.out) st.out[((long)col * st.R + r) * st.outP + st.outS] = acc;
-                    }
-                }
-            }
-        }
+        int off = 0, si = 0;
+        auto run = [&](int R, int K, float scale, const float* bias, float NN, float2* out) {
+            __syncthreads();                                         // the previous stage's output is complete
+            chain_stage_rec(rec + off, V[si & 1], V[(si + 1) & 1], R, K, scale, bias, NN, dc, out, g.Pc, t);
+            off += (R * K + 1) & ~1; ++si;
+        };
+        for (int j = 1; j < L; ++j) { const ChainLevel& w = g.lv[j - 1]; run(w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, nullptr); }
+        { const ChainLevel& w = g.lv[L - 1]; run(w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, nullptr); }
+        for (int j = L - 1; j >= 0; --j) { const ChainLevel& v = g.lv[j]; run(v.dD, v.dM, 1.0f / (float)v.dD, v.p, (float)v.Nx * (float)v.Ny, v.O); }
+        return;
     }
-    // tail: bins of grid 1 that no bin of grid 2 maps to -- A_1 is a gather of C_0 (32 threads per bin)
-    if (g.n_items > g.n_main) {
-        const ChainLevel& w0 = g.lv[0];
-        const ChainLevel& w1 = g.lv[1];
-        const float NN = (float)w0.Nx * (float)w0.Ny, sc = 1.0f / (float)w0.dM;
-        for (int it = g.n_main + blockIdx.x * 8 + (tid >> 5); it < g.n_items; it += gridDim.x * 8) {
-            const int s = g.items[2 * it + 1];
-            const long u = map_up(s, w1.Nx, w1.Ny, w0.Nx, w0.Ny);
-            for (int o = tid & 31; o < w0.dM * OPC; o += 32) {
-                const int m = o / OPC, c = o - m * OPC;
-                float2 v = make_float2(0.f, 0.f);
-                if (c < g.D0) { v = w0.C[((long)m * w0.dD + c) * w0.P + u]; v.x *= sc; v.y *= sc; }
-                else if (c == OPC - 1 && s == 0) v.x = w0.b[m] * NN;
-                w1.A[((long)c * w0.dM + m) * w1.P + s] = v;
+    // ---- planar tile of grid j ----
+    int j = 1;
+#pragma unroll
+    for (int i = 2; i < 8; ++i) if (i < L && (int)blockIdx.x >= g.tile_start[i]) j = i;
+    const int bl = tid % CH_BT, ry = tid / CH_BT;
+    constexpr int RT = 256 / CH_BT;
+    const ChainLevel lj = g.lv[j];
+    const long s0 = (long)(blockIdx.x - g.tile_start[j]) * CH_BT;
+    const long s = min(s0 + bl, lj.P - 1);
+    const bool ok = s0 + bl < lj.P;
+    long sb[8];
+    sb[j] = s;
+#pragma unroll
+    for (int i = 7; i > 0; --i) if (i <= j) sb[i - 1] = map_up(sb[i], g.lv[i].Nx, g.lv[i].Ny, g.lv[i - 1].Nx, g.lv[i - 1].Ny);
+    // V tiles in LDS: [row][col][bin], ping-pong halves of Wl
+    float2* Vt[2] = {Wl, Wl + g.vt_elems};
+    for (int i = tid; i < OPC * OPC * CH_BT; i += 256) { const int b2 = i % CH_BT, c = (i / CH_BT) % OPC, k = i / (CH_BT * OPC); Vt[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); (void)b2; }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        if (i > j) break;
+        const ChainLevel w = g.lv[i - 1];
+        const int R = w.dM, K = w.dD;
+        const float scale = 1.0f / (float)w.dM, NN = (float)w.Nx * (float)w.Ny;
+        const float2* Vin = Vt[(i - 1) & 1];
+        float2* Vout = Vt[i & 1];
+        __syncthreads();
+        for (int r = ry; r < R; r += RT) {
+            float2 acc[OPC];
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
+            const float2* Wp = w.C + (long)r * K * w.P + sb[i - 1];
+            auto grp = [&](int k0, auto NU) {
+                constexpr int U = decltype(NU)::value;
+                float2 wv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) wv[u] = Wp[(long)(k0 + u) * w.P];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < OPC; ++c) cfma2(acc[c], wv[u], Vin[((k0 + u) * OPC + c) * CH_BT + bl]);
+            };
+            int k0 = 0;
+            for (; k0 + 16 <= K; k0 += 16) grp(k0, std::integral_constant<int, 16>{});
+            if (k0 + 8 <= K) { grp(k0, std::integral_constant<int, 8>{}); k0 += 8; }
+            if (k0 + 4 <= K) { grp(k0, std::integral_constant<int, 4>{}); k0 += 4; }
+            if (k0 + 2 <= K) { grp(k0, std::integral_constant<int, 2>{}); k0 += 2; }
+            if (k0 < K) grp(k0, std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
+            if (sb[i] == 0) acc[OPC - 1].x += w.b[r] * NN;
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) {
+                Vout[(r * OPC + c) * CH_BT + bl] = acc[c];
+                if (i == j && ok) lj.A[((long)c * R + r) * lj.P + s] = acc[c];
             }
         }
     }
 }
 
-hipError_t launch_chain(const ChainArgs& g, hipStream_t st)
+hipError_t launch_chain(ChainArgs& g, hipStream_t st)
 {
-    if (g.L < 1 || g.L > 8 || g.n_main < 1) return hipErrorInvalidValue;
-    for (int l = 0; l < g.L; ++l) if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX || g.lv[l].dD > CH_ELEMS || g.lv[l].dM > CH_ELEMS) return hipErrorInvalidValue;
-    chain_kernel<<<dim3((unsigned)g.n_main), 256, 0, st>>>(g);
+    if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
+    for (int l = 0; l < g.L; ++l) {
+        if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX) return hipErrorInvalidValue;
+        if (((g.lv[l].dD * g.lv[l].dM + 1) & ~1) > CH_WL) return hipErrorInvalidValue;
+        if (l + 1 < g.L && (size_t)2 * g.lv[l].dM * OPC * CH_BT > CH_WL) return hipErrorInvalidValue;     // planar tiles: two V tiles share the LDS buffer
+    }
+    long total = g.Pc;
+    for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
+    g.tile_start[g.L] = (int)total;
+    if (total >= (1L << 31)) return hipErrorInvalidValue;
+    int rmax = OPC;
+    for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
+    g.vt_elems = rmax * OPC * CH_BT;
+    const size_t lds = sizeof(float2) * 2 * g.vt_elems;
+    chain_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 

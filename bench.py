@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the short extra runs (cfg3-P1, spatial mode) reported under \"variants\"")
+    ap.add_argument("--flags", default="", help="comma-separated development switches (include/aefft.h AEFFT_F_*), e.g. NOOVERLAP,NOOPFORM")
     ap.add_argument("--rccl", action="store_true", help="initialise the nccl (RCCL) process group even at N = 1")
     ap.add_argument("--torch-stream", action="store_true", help="enqueue on torch's current (legacy default) stream instead of a private stream")
     return ap.parse_args()
@@ -166,6 +167,8 @@ def main():
         assert dist.get_world_size() == world
     aefft = importlib.import_module("autoencoder-fft_amd")
     ctx = aefft.Context(local, use_torch_stream=a.torch_stream)
+    if a.flags:
+        ctx.set_flags(*a.flags.split(","))
     N, D, maps, Nk = a.size, 3, [8, 16, 32, 64], 5
     s = 2 if a.variant == "p2" else 1
     B = a.batch
