@@ -60,6 +60,7 @@ SIGNATURES = {
     "aefft_update": (_i, [_vp] + [_fp] * 14 + [_i] * 6 + [_f, _i]),
     "aefft_conv_spatial": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i]),
     "aefft_pool_spatial": (_i, [_vp, _fp, _fp, C.c_long, _i, _i, _i, _i, _i]),
+    "aefft_pool_conv_spatial": (_i, [_vp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9),
     "aefft_backprop_spatial": (_i, [_vp] + [_fp] * 15 + [_i] * 7 + [_f, _f, _i, _i]),
     "aefft_net_create": (_i, [_vp, C.POINTER(NetDesc), C.POINTER(_vp)]),
     "aefft_net_destroy": (None, [_vp]),
@@ -70,6 +71,9 @@ SIGNATURES = {
     "aefft_net_store_spectra": (_i, [_vp, _i, _vp, _vp]),
     "aefft_net_forward": (_i, [_vp, _fp, _fp]),
     "aefft_net_get_layer": (_i, [_vp, _i, _fp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "aefft_net_layers_layout": (_i, [_vp, C.POINTER(C.c_size_t)]),
+    "aefft_net_get_layers": (_i, [_vp, _fp]),
+    "aefft_magnitude": (_i, [_vp, _fp, _fp, _l, _i, _i, _i, _i]),
     "aefft_net_train_pair": (_i, [_vp, _i, _i, _f, _i, _i, _vp]),
     "aefft_net_step_grad": (_i, [_vp, _fp, _fp]),
     "aefft_net_set_input_ready": (_i, [_vp, _i]),
@@ -250,6 +254,13 @@ class Context:
                                        _ptr(db), _ptr(dp), _ptr(Dc), _ptr(Df), _ptr(Db), _ptr(Dp),
                                        dM, dD, Nx, Ny, Nk, Nl, dele, maxdiff))
 
+    def magnitude(self, X, Ny, ch, shift=False):
+        *lead, Nx, Nyr = X.shape
+        planes = int(np.prod(lead)) if lead else 1
+        mag = self.empty(*lead, Nx, Ny)
+        self.check(self.L.aefft_magnitude(self.h, _ptr(X), _ptr(mag), planes, ch, Nx, Ny, 1 if shift else 0))
+        return mag
+
     def conv_spatial(self, x, c, b, semantics="gpu"):
         B, dD, Nx, Ny = x.shape
         dM, _, Nk, Nl = c.shape
@@ -265,6 +276,17 @@ class Context:
         planes = int(np.prod(x.shape[:-2]))
         self.check(self.L.aefft_pool_spatial(self.h, _ptr(x), _ptr(out), planes, x.shape[-2], x.shape[-1], out_shape[0], out_shape[1], scale))
         return out
+
+    def pool_conv_spatial(self, x, c, b, scale, semantics="gpu", want_pooled=True):
+        """Pool(scale) + Conv_gpu in one launch; returns (pooled layer or None, conv output)."""
+        B, dD, Nxi, Nyi = x.shape
+        dM, _, Nk, Nl = c.shape
+        Nx, Ny = Nxi // scale, Nyi // scale
+        pooled = self.empty(B, dD, Nx, Ny) if want_pooled else None
+        out = self.empty(B, dM, Nx, Ny)
+        self.check(self.L.aefft_pool_conv_spatial(self.h, _ptr(x), _ptr(pooled), _ptr(out), _ptr(c), _ptr(b), B, dD, dM, Nx, Ny, scale, Nk, Nl,
+                                                  0 if semantics == "gpu" else 1))
+        return pooled, out
 
     def backprop_spatial(self, x, out, hin, c, b, f, p, mom, grads, delmax, alpha, tied=False, semantics="gpu"):
         """mom = (dc, db, df, dp), grads = (ddc, ddb, ddf, ddp): torch tensors updated in place."""
@@ -374,6 +396,20 @@ class Net:
         self.ctx.check(self.L.aefft_net_get_layer(self.h, layer, None, C.byref(ch), C.byref(nx), C.byref(ny)))
         out = self.ctx.empty(self.B, ch.value, nx.value, ny.value)
         self.ctx.check(self.L.aefft_net_get_layer(self.h, layer, _ptr(out), None, None, None))
+        return out
+
+    def get_layers(self):
+        """every layer 0..4L of the last forward in one call: list of torch views into one packed buffer"""
+        nl = 4 * self.npairs + 1
+        offs = (C.c_size_t * (nl + 1))()
+        self.ctx.check(self.L.aefft_net_layers_layout(self.h, offs))
+        buf = self.ctx.empty(int(offs[nl]))
+        self.ctx.check(self.L.aefft_net_get_layers(self.h, _ptr(buf)))
+        out = []
+        for l in range(nl):
+            ch, nx, ny = C.c_int(), C.c_int(), C.c_int()
+            self.ctx.check(self.L.aefft_net_get_layer(self.h, l, None, C.byref(ch), C.byref(nx), C.byref(ny)))
+            out.append(buf[int(offs[l]):int(offs[l + 1])].view(self.B, ch.value, nx.value, ny.value))
         return out
 
     def train_pair(self, l, n_iter, del0, maxdiff=0, sym=0):

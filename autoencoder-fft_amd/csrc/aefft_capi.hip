@@ -800,6 +800,20 @@ extern "C" int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_
     return AEFFT_OK;
 }
 
+extern "C" int aefft_pool_conv_spatial(aefft_ctx* ctx, const float* in_d, float* pooled_d, float* out_d, const float* c_d, const float* b_d,
+                                       int B, int dD, int dM, int Nx, int Ny, int scale, int Nk, int Nl, int cpu_semantics)
+{
+    if (!ctx || !in_d || !out_d || !c_d || !b_d || B <= 0 || dD <= 0 || dM <= 0 || Nx <= 0 || Ny <= 0 || Nk <= 0 || Nl <= 0 || scale < 1)
+        return fail(ctx, AEFFT_EINVAL, "aefft_pool_conv_spatial: bad argument");
+    int ak, al, lo;
+    spatial_geom(Nk, Nl, cpu_semantics, &ak, &al, &lo);
+    Bracket br(ctx, KID_SPATIAL, ((double)B * dD * Nx * Ny * scale * scale + (double)B * (dM + (pooled_d ? dD : 0)) * Nx * Ny + (double)dM * dD * Nk * Nl) * 4.0);
+    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics ? 1.f : (float)dM, lo, ctx->stream, scale, pooled_d);
+    if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return fail(ctx, AEFFT_EINVAL, "aefft_pool_conv_spatial: kernel shape not served by the fused kernel"); }
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "pool_conv_spatial", e);
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_pool_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale)
 {
     if (!ctx || !in_d || !out_d || planes <= 0 || Nxi <= 0 || Nyi <= 0 || Nxo <= 0 || Nyo <= 0 || scale == 0)
@@ -1471,6 +1485,42 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     }
     RET_IF(do_c2r(ctx, S, out_d, (long)B * c, xi, yi, x, y, 1.0f / ((float)x * (float)y)));
     return mark_step_point(n);
+}
+
+extern "C" int aefft_magnitude(aefft_ctx* ctx, const float* X_d, float* mag_d, long planes, int ch, int Nx, int Ny, int shift)
+{
+    if (!ctx || !X_d || !mag_d || planes <= 0 || ch <= 0 || Nx <= 0 || Ny <= 1) return fail(ctx, AEFFT_EINVAL, "aefft_magnitude: bad argument");
+    Bracket br(ctx, KID_RESIZE, (double)planes * ((double)Nx * (Ny / 2 + 1) * 8.0 + (double)Nx * Ny * 4.0));
+    hipError_t e = launch_magnitude(CF2(X_d), mag_d, planes, ch, Nx, Ny, shift, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "magnitude", e);
+    return AEFFT_OK;
+}
+
+extern "C" int aefft_net_layers_layout(aefft_net* n, size_t* offsets_h)
+{
+    if (!n || !offsets_h) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_layers_layout: bad argument");
+    size_t off = 0;
+    for (int l = 0; l <= 4 * n->L; ++l) {
+        int c, x, y;
+        RET_IF(aefft_net_get_layer(n, l, nullptr, &c, &x, &y));
+        offsets_h[l] = off;
+        off += (size_t)n->B * c * x * y;
+    }
+    offsets_h[4 * n->L + 1] = off;
+    return AEFFT_OK;
+}
+
+// All layers of the last forward in coordinate space (fft_l = 1, fft_backproplib.cu:1347,1357,1361).  A decoder conv output and
+// the up-sampled layer after it are inverse transforms of the SAME spectrum onto two grids; an encoder's pooled input and the
+// previous hidden layer likewise -- each stored spectrum is read where it lies, the crop / zero-pad is fused into the transform.
+extern "C" int aefft_net_get_layers(aefft_net* n, float* out_d)
+{
+    if (!n || !out_d) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_get_layers: bad argument");
+    if (!n->have_forward) return fail(n->ctx, AEFFT_ESTATE, "aefft_net_get_layers: no forward pass yet");
+    std::vector<size_t> off(4 * n->L + 2);
+    RET_IF(aefft_net_layers_layout(n, off.data()));
+    for (int l = 0; l <= 4 * n->L; ++l) RET_IF(aefft_net_get_layer(n, l, out_d + off[l], nullptr, nullptr, nullptr));
+    return AEFFT_OK;
 }
 
 // expand a decoder output that the training-step forward kept on its support only

@@ -82,6 +82,7 @@ hipError_t launch_contract_group(ContractN& g, int cls, hipStream_t st);
 hipError_t launch_contract(const Contract& q, hipStream_t st);
 
 hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st);
+hipError_t launch_magnitude(const float2* X, float* mag, long planes, int ch, int Nx, int Ny, int shift, hipStream_t st);   // fft.cu:27-63
 // E = O - T and MSE (fft.cu:480-498): *mse_acc += scale * sum_bins |T-O|^2/n_bin.
 hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E /*nullable*/, float* mse_acc /*1 float, pre-zeroed, nullable*/,
                            float* es /*[2*ch] floats, pre-zeroed, nullable: sum_b E_b[d](0,0)*/, int B, int ch, int Nx, int Ny, float scale, hipStream_t st);
@@ -193,7 +194,8 @@ hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, 
 
 // ---- spatial_kernels.hip ---------------------------------------------------------------
 hipError_t launch_conv_spatial(const float* in, float* out, const float* c, const float* b, int B, int dD, int dM,
-                               int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st);
+                               int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st,
+                               int pool = 0 /* fused Pool(scale) in front: `in` is [B][dD][Nx*pool][Ny*pool] */, float* pooled_out = nullptr);
 struct SpatialGradArgs {
     const float *in, *out, *hin, *f;      // [dD][Nx][Ny], [dD][Nx][Ny], [dM][Nx][Ny], [dD][dM][Nk][Nl]
     float *gc, *gf, *gb, *gp;             // [dM][dD][Nk][Nl], [dD][dM][Nk][Nl], [dM], [dD]

@@ -159,14 +159,18 @@ void autoenc_fft(Kernels& layers, KernelStack& net_c, BiasStack& net_cfreq, Bias
     frames.up(x);
     chk(aefft_net_forward(net, frames.d, recon.d), "aefft_net_forward");
     if (fft_l) {
+        // fft_l = 1 (fft_backproplib.cu:1347,1357,1361): every layer in ONE call and one download
+        std::vector<size_t> off(4 * L + 2);
+        chk(aefft_net_layers_layout(net, off.data()), "aefft_net_layers_layout");
+        std::vector<float> all(off[4 * L + 1]);
+        DevBuf d(all.size());
+        chk(aefft_net_get_layers(net, d.d), "aefft_net_get_layers");
+        d.down(all);
         for (int l = 1; l <= 4 * L; ++l) {
-            int ch, lx, ly;
-            chk(aefft_net_get_layer(net, l, nullptr, &ch, &lx, &ly), "aefft_net_get_layer");
-            if ((int)layers[l].size() != ch || (int)layers[l][0].size() != lx || (int)layers[l][0][0].size() != ly) die("autoenc_fft", "layers[l] is not pre-sized to the network's shape");
-            std::vector<float> h((size_t)ch * lx * ly);
-            DevBuf d(h.size());
-            chk(aefft_net_get_layer(net, l, d.d, nullptr, nullptr, nullptr), "aefft_net_get_layer");
-            d.down(h);
+            const size_t sz = off[l + 1] - off[l];
+            if (layers[l].empty() || layers[l][0].empty() || (size_t)layers[l].size() * layers[l][0].size() * layers[l][0][0].size() != sz)
+                die("autoenc_fft", "layers[l] is not pre-sized to the network's shape");
+            std::vector<float> h(all.begin() + off[l], all.begin() + off[l + 1]);
             unflat3(h, layers[l]);
         }
     } else {

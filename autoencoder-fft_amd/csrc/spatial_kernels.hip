@@ -70,6 +70,10 @@ struct DConvArgs {
     int sgn;                    // -1: input index = i - offset (conv_parallel); +1: i + offset (back-convolution through f)
     int lo_in, hi_lo;           // valid input indices [lo_in, N); outputs with i < hi_lo or j < hi_lo are 0 (back-conv with lo = 1)
     float div;                  // input divided by this while staging (1: none)
+    // fused Pool (netlib.cpp:114-164, scale > 0) in front of the convolution: `in` is the UN-pooled plane [Din][Nx*pool][Ny*pool]
+    // and every staged input pixel is max(0, trunc(max of its pool x pool window)); pooled_out (nullable) also receives the pooled
+    // layer [B][Din][Nx][Ny] (the training step needs it as the pair's input).  pool == 0: off.
+    int pool; float* pooled_out;
 };
 
 template <int TM, int NK>
@@ -142,6 +146,153 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// mconv_kernel<MB,NK>: the same convolution as an IMPLICIT GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+//     out[m][pixel] = sum_{(d,k,l)} w[m][(d,k,l)] * in[d][pixel shifted by (k,l)]        M = maps, N = pixels, K = Din*NK*NK
+// A = weights (rows = 32 maps of a block, k = 2 consecutive (d,k,l) indices), B = input pixels (cols = 32 pixels of one tile row,
+// same 2 k), gathered per lane from the LDS input tile -- the im2col matrix is never materialised.  A workgroup owns an
+// 8-row x 32-column pixel tile x 32*MB maps of one frame; wave w owns tile rows 2w, 2w+1, i.e. 2*MB accumulator blocks of 32x32;
+// per k-step it reads 2 B operands and MB A operands from LDS for 2*MB MFMAs of 2048 MACs.  The D layout puts the 32 pixels of a
+// row on consecutive lanes: every store instruction writes two full 128-byte lines (the 16-pixel tiles of the VALU kernel write
+// 64-byte runs, and this layer is bound by its output stream).  Input channels are staged DC at a time together with their weight
+// slab wl[(d,k,l)][map] (zero-filled beyond K and M, so padded k-steps and map blocks contribute nothing).  Range tests, the
+// out-in subtraction, the /dM of Conv_gpu (backproplib.cu:134) and the optional Pool are applied while staging, as in
+// dconv_kernel.  The sums run over (d,k,l) in pairs instead of one at a time: float32 rounding only.
+// ------------------------------------------------------------------------------------------
+typedef float v16f_s __attribute__((ext_vector_type(16)));
+
+template <int NK> struct MConvCfg { static constexpr int DC = NK == 3 ? 8 : (NK == 5 ? 4 : 2), KK = NK * NK, KC = DC * KK, KCP = (KC + 1) & ~1; };
+
+template <int MB, int NK>
+__global__ __launch_bounds__(256) void mconv_kernel(const DConvArgs a)
+{
+    using Cfg = MConvCfg<NK>;
+    constexpr int TR = 8, TC = 32, TWY = TR + NK - 1, TWX = TC + NK - 1, TSZ = TWY * TWX;
+    constexpr int DC = Cfg::DC, KK = Cfg::KK, KCP = Cfg::KCP, MT = 32 * MB;
+    __shared__ float tile[DC][TSZ];
+    __shared__ float wl[KCP][MT];
+    const int tiles_y = (a.Ny + TC - 1) / TC;
+    const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
+    const int m0 = blockIdx.y * MT;
+    const long bb = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kq = lane >> 5;
+    const int r0 = a.sgn < 0 ? ti * TR - a.ik0 - (NK - 1) : ti * TR + a.ik0;
+    const int c0 = a.sgn < 0 ? tj * TC - a.il0 - (NK - 1) : tj * TC + a.il0;
+    const long plane = (long)a.Nx * a.Ny;
+    v16f_s acc[2][MB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][mb][e] = 0.f;
+    for (int d0 = 0; d0 < a.Din; d0 += DC) {
+        const int nd = min(DC, a.Din - d0);
+        const int nk = nd * KK;
+        __syncthreads();
+        if (a.pool) {
+            const int s = a.pool, Nxi = a.Nx * s, Nyi = a.Ny * s;
+            for (int t = threadIdx.x; t < nd * TSZ; t += 256) {
+                const int dl = t / TSZ, q = t - dl * TSZ;
+                const int r = r0 + q / TWX, cc = c0 + q % TWX;
+                float x = 0.f;
+                if (r >= 0 && r < a.Nx && cc >= 0 && cc < a.Ny) {
+                    const float* src = a.in + ((bb * a.Din + d0 + dl) * (long)Nxi + (long)r * s) * Nyi + (long)cc * s;
+                    float mx = 0.f;
+                    for (int k = 0; k < s; ++k)
+                        for (int l = 0; l < s; ++l) mx = fmaxf(mx, src[(long)k * Nyi + l]);
+                    x = (float)(int)mx;                                       // `int smax = 0` accumulator of netlib.cpp:127-136
+                    // the tile's own pixels (not the halo) of map block 0 also publish the pooled layer
+                    if (a.pooled_out && blockIdx.y == 0 && r >= ti * TR && r < ti * TR + TR && cc >= tj * TC && cc < tj * TC + TC)
+                        a.pooled_out[(bb * a.Din + d0 + dl) * plane + (long)r * a.Ny + cc] = x;
+                    if (r < a.lo_in || cc < a.lo_in) x = 0.f;                 // the convolution's own range test ('>0' of netlib.cpp:344)
+                }
+                tile[dl][q] = a.div != 1.f ? x / a.div : x;
+            }
+        } else {
+            for (int t0 = 0; t0 < nd * TSZ; t0 += 256 * 8) {
+                float v[8], v2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u * 256 + threadIdx.x;
+                    const int dl = min(t / TSZ, nd - 1), q = t % TSZ;
+                    const int r = r0 + q / TWX, cc = c0 + q % TWX;
+                    const bool ok = t < nd * TSZ && r >= a.lo_in && r < a.Nx && cc >= a.lo_in && cc < a.Ny;
+                    const long idx = ok ? (bb * a.Din + d0 + dl) * plane + (long)r * a.Ny + cc : 0;
+                    v[u] = a.in[idx];
+                    v2[u] = a.in2 ? a.in2[idx] : 0.f;
+                    if (!ok) { v[u] = 0.f; v2[u] = 0.f; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u * 256 + threadIdx.x;
+                    if (t >= nd * TSZ) break;
+                    float x = v[u] - v2[u];
+                    if (a.div != 1.f) x = x / a.div;
+                    tile[t / TSZ][t % TSZ] = x;
+                }
+            }
+        }
+        // weight slab of the chunk: wl[(dl,k,l)][map], zero beyond the chunk's K and the layer's M
+        const int nkp = (nk + 1) & ~1;
+        for (int t0 = 0; t0 < nkp * MT; t0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256 + threadIdx.x;
+                const int kidx = min(t / MT, KCP - 1), ml = t % MT;
+                const bool ok = t < nkp * MT && kidx < nk && m0 + ml < a.M;
+                const int dl = kidx / KK, kl = kidx - dl * KK;
+                v[u] = ok ? a.w[(long)(m0 + ml) * a.w_m + (long)(d0 + dl) * a.w_d + kl] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < nkp * MT) wl[t / MT][t % MT] = v[u]; }
+        }
+        __syncthreads();
+        for (int ks = 0; ks < nk; ks += 2) {
+            const int kidx = min(ks + kq, nk - 1);                      // (beyond nk the weights are zero)
+            const int dl = kidx / KK, kl = kidx - dl * KK;
+            const int kr = kl / NK, lc = kl - kr * NK;
+            const int rr = a.sgn < 0 ? NK - 1 - kr : kr, cc = a.sgn < 0 ? NK - 1 - lc : lc;
+            const float* tp = &tile[dl][(2 * wv + rr) * TWX + col + cc];
+            float bv[2], av[MB];
+            bv[0] = tp[0]; bv[1] = tp[TWX];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = wl[ks + kq][32 * mb + col];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[r][mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[r], acc[r][mb], 0, 0, 0);
+        }
+    }
+    // D layout (32x32): lane holds column (pixel) lane&31 of rows (maps) (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int j = tj * TC + col;
+    if (j >= a.Ny) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = ti * TR + 2 * wv + r;
+        if (i >= a.Nx) continue;
+        const bool zero = i < a.hi_lo || j < a.hi_lo;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * mb + (e & 3) + 8 * (e >> 2) + 4 * kq;
+                if (m >= a.M) continue;
+                a.out[(bb * a.M + m) * plane + (long)i * a.Ny + j] = zero ? 0.f : acc[r][mb][e] + (a.bias ? a.bias[m] : 0.f);
+            }
+    }
+}
+
+template <int NK> static hipError_t run_mconv(const DConvArgs& a, int B, hipStream_t st)
+{
+    const int tiles = ((a.Nx + 7) / 8) * ((a.Ny + 31) / 32);
+    if (a.M > 32) mconv_kernel<2, NK><<<dim3(tiles, (a.M + 63) / 64, B), 256, 0, st>>>(a);
+    else mconv_kernel<1, NK><<<dim3(tiles, (a.M + 31) / 32, B), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
 template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStream_t st)
 {
     const int tiles = ((a.Nx + 15) / 16) * ((a.Ny + 15) / 16);
@@ -153,6 +304,13 @@ template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStre
 static bool dconv_ok(int Nk, int Nl, int B) { return Nk == Nl && (Nk == 3 || Nk == 5 || Nk == 7) && B <= 65535; }
 static hipError_t launch_dconv(const DConvArgs& a, int Nk, int B, hipStream_t st)
 {
+    // matrix cores whenever there is a GEMM to speak of (>= 8 maps); AEFFT_F_NOMFMA keeps the VALU tile kernel (and the fused
+    // Pool exists only in the matrix-core kernel)
+    if ((a.M >= 8 && !flag(AEFFT_F_NOMFMA)) || a.pool) {
+        if (Nk == 3) return run_mconv<3>(a, B, st);
+        if (Nk == 5) return run_mconv<5>(a, B, st);
+        return run_mconv<7>(a, B, st);
+    }
     if (Nk == 3) return run_dconv<3>(a, B, st);
     if (Nk == 5) return run_dconv<5>(a, B, st);
     return run_dconv<7>(a, B, st);
@@ -321,7 +479,8 @@ template <int NK> static hipError_t launch_wcorr(const WCorrArgs& a, int B, floa
 }
 
 hipError_t launch_conv_spatial(const float* in, float* out, const float* c, const float* b, int B, int dD, int dM,
-                               int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st)
+                               int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st,
+                               int pool, float* pooled_out)
 {
     const long total = (long)B * dM * Nx * Ny;
     if (total <= 0) return hipSuccess;
@@ -330,8 +489,10 @@ hipError_t launch_conv_spatial(const float* in, float* out, const float* c, cons
         a.in = in; a.w = c; a.bias = b; a.out = out;
         a.Din = dD; a.M = dM; a.Nx = Nx; a.Ny = Ny; a.w_m = dD * Nk * Nl; a.w_d = Nk * Nl;
         a.ik0 = -2 * ak - 1; a.il0 = -2 * al - 1; a.sgn = -1; a.lo_in = lo; a.hi_lo = 0; a.div = in_scale_div;
+        a.pool = pool; a.pooled_out = pooled_out;
         return launch_dconv(a, Nk, B, st);
     }
+    if (pool) return hipErrorInvalidValue;                             // (callers pool separately for shapes the tiled kernels do not serve)
     conv_spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(in, out, c, b, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, in_scale_div, lo);
     return hipGetLastError();
 }

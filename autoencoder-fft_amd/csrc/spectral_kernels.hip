@@ -670,6 +670,33 @@ hipError_t launch_resize(const float2* in, float2* out, long planes, int Nx, int
 }
 
 // ------------------------------------------------------------------------------------------
+// spectrum display (fft_backproplib.cu:27-63): `magnitude` followed by `shift_magnitude`, fused.  Output pixel (i, j) takes
+// the magnitude at (i', j') = the quadrant-swapped position when shift != 0 (:33-36), else (i, j); the magnitude itself is
+// sqrt(|X| / Ntot) of X[i'][j'] for j' < Nyr and of the mirrored element X[Nx-1-i'][2*Nyr-1-j'] otherwise (:52-53, literally).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void magnitude_kernel(const float2* __restrict__ X, float* __restrict__ mag, unsigned planes, int ch, int Nx, int Ny, int shift)
+{
+    const unsigned Nyr = Ny / 2 + 1, psz = (unsigned)Nx * Ny;
+    const unsigned total = planes * psz;
+    const float inv = 1.0f / ((float)ch * (float)Nx * (float)Ny);
+    for (unsigned idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const unsigned d = idx / psz, rem = idx - d * psz;
+        int i = (int)(rem / (unsigned)Ny), j = (int)(rem - (unsigned)i * Ny);
+        if (shift) { i = i < Nx / 2 ? i + Nx / 2 : i - Nx / 2; j = j < Ny / 2 ? j + Ny / 2 : j - Ny / 2; }
+        const float2 v = j < (int)Nyr ? X[((size_t)d * Nx + i) * Nyr + j] : X[((size_t)d * Nx + (Nx - 1 - i)) * Nyr + (2 * Nyr - 1 - j)];
+        mag[idx] = sqrtf(sqrtf(v.x * v.x + v.y * v.y) * inv);
+    }
+}
+hipError_t launch_magnitude(const float2* X, float* mag, long planes, int ch, int Nx, int Ny, int shift, hipStream_t st)
+{
+    const long total = planes * Nx * Ny;
+    if (total <= 0) return hipSuccess;
+    if (total >= (1L << 32) || ch < 1) return hipErrorInvalidValue;
+    magnitude_kernel<<<dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), 256, 0, st>>>(X, mag, (unsigned)planes, ch, Nx, Ny, shift);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // E = O - T, and the spectral MSE (fft_backproplib.cu:480-498 + 1188-1190):
 //   mse = sum_bins |T-O|^2 / n_bin / (2*dM*Nx*Ny),  n_bin = dD*Nx*Ny, halved for columns 0<j<Nyr-1.
 // For a batch the mean over frames is accumulated: *mse_acc += partial * scale.

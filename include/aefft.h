@@ -135,6 +135,12 @@ int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, const fl
  * integer accumulator (`int smax = 0`: result = max(0, trunc(window maximum)), also at scale 1); scale < 0 up-samples by
  * nearest neighbour.  in_d [planes][Nxi][Nyi] -> out_d [planes][Nxo][Nyo]; outputs the reference loop never writes stay untouched. */
 int aefft_pool_spatial(aefft_ctx* ctx, const float* in_d, float* out_d, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale);
+/* Pool(scale >= 1) followed by Conv_gpu in ONE launch (autoencoder.cpp:135-150 calls them back to back and
+ * bounces the pooled layer through host vectors).  in_d [B][dD][Nx*scale][Ny*scale]; pooled_d (nullable) also receives the pooled
+ * layer [B][dD][Nx][Ny] -- the training step needs it as the pair's input; out_d [B][dM][Nx][Ny].  Served for square 3x3 / 5x5 /
+ * 7x7 kernels (AEFFT_EINVAL otherwise: pool and convolve separately). */
+int aefft_pool_conv_spatial(aefft_ctx* ctx, const float* in_d, float* pooled_d, float* out_d, const float* c_d, const float* b_d,
+                            int B, int dD, int dM, int Nx, int Ny, int scale, int Nk, int Nl, int cpu_semantics);
 /* backproplib.cu:291-418 `backprop_gpu` (tied=0) / :521-644 `backprop_gpu_cc` (tied=1): back-conv
  * through f + weight-gradient correlation, then the inertia update
  *   d <- (1-alpha)*delmax*g/max(10,|g|) + alpha*d ; w <- w - d     (:392-396)
@@ -181,6 +187,17 @@ int aefft_net_forward(aefft_net* net, const float* frames_d, float* recon_d);
  * (autoencoder.cpp:110-114 ordering, 0..4L) from the last forward.  out_d [B][ch][nx][ny];
  * ch/nx/ny (nullable) receive its shape.  Pass out_d=NULL to query the shape only. */
 int aefft_net_get_layer(aefft_net* net, int layer, float* out_d, int* ch, int* nx, int* ny);
+
+/* fft_l = 1 in one call: EVERY layer 0..4L of the last forward, coordinate space, packed into out_d at the
+ * offsets aefft_net_layers_layout reports (floats; offsets_h[4L+1] = total).  Each layer is one inverse transform of the spectrum
+ * where it is stored (spectral crop / zero-pad fused); hidden layers the training step skipped are formed first. */
+int aefft_net_layers_layout(aefft_net* net, size_t* offsets_h /* [4L+2] */);
+int aefft_net_get_layers(aefft_net* net, float* out_d);
+/* fft_backproplib.cu:27-63 `magnitude` + `shift_magnitude` (the reference's spectrum display path, dead in its main()):
+ * mag[d][i][j] = sqrt(|X[d][i][j]| / (ch*Nx*Ny)) on the half-plane j < Nyr, the mirrored element
+ * X[d][Nx-1-i][2*Nyr-1-j] beyond it (the reference's index arithmetic, :53), shift != 0: quadrants swapped so that the zero
+ * frequency sits in the centre (:33-36).  X_d [planes][Nx][Nyr] -> mag_d [planes][Nx][Ny]; ch = channels per frame. */
+int aefft_magnitude(aefft_ctx* ctx, const float* X_d, float* mag_d, long planes, int ch, int Nx, int Ny, int shift);
 
 /* fft_backproplib.cu:1381-1511 `backprop_fft` burst on pair l, using the spectra of the last
  * forward as in / expout(=in) / out (autoencoder.cpp:169,194): zeroes the momentum (:1420-1423),

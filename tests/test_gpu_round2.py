@@ -210,3 +210,46 @@ def test_default_rate_burst_diverges_no_earlier_than_the_float32_replay(ctx, see
     print(f"first divergence > 1e-3 of the float64 master: HIP at iteration {k_hip}, float32 replay at {k_f32}")
     assert k_hip >= min(int(0.6 * k_f32), 100), (k_hip, k_f32)
     assert 0.5 < mse[-1] / float(r32["mse"][-1]) < 2.0
+
+
+def test_batched_layer_export_and_magnitude(ctx):
+    """every layer of fft_l = 1 in one call == the per-layer exports == the oracle; and the reference's spectrum
+    display kernels (`magnitude` + `shift_magnitude`, fft_backproplib.cu:27-63) restated in numpy."""
+    rng = np.random.default_rng(44)
+    D, N, maps, Nk, s, B = 3, 32, [4, 6], 5, 2, 2
+    L = len(maps)
+    ws = _weights(rng, D, maps, Nk)
+    xs = np.floor(rng.uniform(0, 256, (B, D, N, N)))
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(ws):
+        net.set_pair(l, *w)
+    net.forward(ctx.dev(xs), None)
+    layers = net.get_layers()
+    assert len(layers) == 4 * L + 1
+    net_c = [w[0] for w in ws] + [w[2] for w in ws[::-1]]
+    net_b = [w[1] for w in ws] + [w[3] for w in ws[::-1]]
+    for b in range(B):
+        ref, _, _ = R.autoenc_fft(xs[b], net_c, net_b, [s] * L + [-s] * L)
+        for l in range(4 * L + 1):
+            assert relerr(host(layers[l])[b], ref[l]) < 1e-4, l
+    for l in range(4 * L + 1):
+        assert np.array_equal(host(layers[l]), host(net.get_layer(l)))
+    # after a training step (operator form: the activation buffers hold operators) the export still returns per-frame layers
+    net.step_grad(ctx.dev(xs), None)
+    again = net.get_layers()
+    for l in range(4 * L + 1):
+        assert relerr(host(again[l]), host(layers[l])) < 2e-5, l
+    net.close()
+    # magnitude / shift
+    Nx, Ny, ch = 16, 8, 3
+    X = R.fft(rng.uniform(0, 255, (2, ch, Nx, Ny)))
+    Nyr = Ny // 2 + 1
+    mag = np.zeros((2, ch, Nx, Ny))
+    for i in range(Nx):
+        for j in range(Ny):
+            src = X[..., i, j] if j < Nyr else X[..., Nx - 1 - i, 2 * Nyr - 1 - j]
+            mag[..., i, j] = np.sqrt(np.abs(src) / (ch * Nx * Ny))
+    got = host(ctx.magnitude(ctx.dev(X), Ny, ch))
+    assert relerr(got, mag) < 1e-5
+    got_s = host(ctx.magnitude(ctx.dev(X), Ny, ch, shift=True))
+    assert relerr(got_s, np.roll(mag, (Nx // 2, Ny // 2), axis=(-2, -1))) < 1e-5

@@ -109,3 +109,63 @@ def test_pool_on_device_is_bit_identical_to_the_reference_pool(ctx, N, scale):
     ref = L.pool(x, shape, scale)
     got = host(ctx.pool_spatial(ctx.dev(x), shape[1:], scale))
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dD,dM,N,Nk,B", [(3, 50, 64, 3, 2), (3, 10, 48, 5, 1), (10, 50, 32, 3, 1), (16, 32, 40, 5, 2), (4, 70, 24, 7, 1)])
+def test_conv_matrix_core_kernel_vs_oracle_and_vs_valu_kernel(ctx, dD, dM, N, Nk, B):
+    """a13 as an implicit GEMM on the matrix cores (mconv_kernel: M = maps, N = pixels, K = dD*Nk*Nl): against the oracle, and
+    against the VALU tile kernel (NOMFMA) -- two independent implementations of the same sums; map counts that are not multiples
+    of 16, K not a multiple of 4, several channel chunks, ragged tiles."""
+    x, c, b, f, p = _case(np.random.default_rng(dD * 3 + dM + N), dD, dM, N, Nk, B)
+    got = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b)))
+    ctx.set_flags("NOMFMA")
+    try:
+        valu = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b)))
+    finally:
+        ctx.set_flags()
+    for i in range(B):
+        ref = S.conv(x[i], c, b)
+        assert np.abs(got[i] - ref).max() < 1e-5 * max(1, np.abs(ref).max())
+    assert np.abs(got - valu).max() < 1e-5 * np.abs(valu).max()
+
+
+@pytest.mark.parametrize("dD,dM,N,Nk,s,sem", [(3, 10, 64, 3, 2, "gpu"), (1, 4, 64, 5, 4, "gpu"), (3, 20, 32, 3, 1, "cpu"), (2, 9, 48, 7, 2, "cpu")])
+def test_fused_pool_conv_equals_pool_then_conv(ctx, dD, dM, N, Nk, s, sem):
+    """Pool + Conv in one launch == the reference's Pool (compiled, integer accumulator) followed by the conv, and
+    the pooled layer it publishes is bit-identical to Pool's."""
+    L = cpu.reference() or cpu.port()
+    rng = np.random.default_rng(N + Nk + s)
+    B = 2
+    x = rng.uniform(-40, 260, (B, dD, N, N)).astype(np.float32)
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nk)).astype(np.float32); b = rng.uniform(-1, 1, dM).astype(np.float32)
+    pooled, out = ctx.pool_conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b), s, semantics=sem)
+    n = N // s
+    for i in range(B):
+        pref = L.pool(x[i], (dD, n, n), s)
+        assert np.array_equal(host(pooled)[i], pref)
+        ref = S.conv(pref, c, b, cpu_semantics=(sem == "cpu"))
+        assert np.abs(host(out)[i] - ref).max() < 1e-5 * max(1, np.abs(ref).max())
+    # and without publishing the pooled layer
+    _, out2 = ctx.pool_conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b), s, semantics=sem, want_pooled=False)
+    assert np.array_equal(host(out2), host(out))
+
+
+@pytest.mark.parametrize("dD,dM,N,Nk,B,tied", [(1, 4, 128, 3, 1, False), (3, 8, 256, 3, 2, False), (3, 6, 128, 5, 1, True)])
+def test_backprop_gpu_many_bands(ctx, dD, dM, N, Nk, B, tied):
+    """a14/a15 at config-1 size and beyond: 8-16 row bands per frame, several column tiles, several frames -- the partial-sum
+    buffers of the correlation kernels and their fixed-order reduction (wsum_kernel) against the oracle."""
+    rng = np.random.default_rng(N + Nk + dM)
+    x, c, b, f, p = _case(rng, dD, dM, N, Nk, B)
+    hin = np.stack([S.conv(x[i], c, b) for i in range(B)]).astype(np.float32)
+    out = np.stack([S.conv(hin[i], f, p) for i in range(B)]).astype(np.float32)
+    mom = [np.zeros_like(a) for a in (c, b, f, p)]
+    ref = S.backprop_gpu(list(x), list(out), list(hin), c, b, f, p, mom[0], mom[1], mom[2], mom[3], 0.2, 0.9, tied=tied, B_mean=True)
+    t = [ctx.dev(a) for a in (x, out, hin, c, b, f, p)]
+    tm = [ctx.dev(a) for a in mom]
+    tg = [ctx.dev(np.zeros_like(a)) for a in (c, b, f, p)]
+    ctx.backprop_spatial(*t, tm, tg, 0.2, 0.9, tied=tied)
+    names = ["ddc", "ddb", "ddf", "ddp"]
+    for k, g, r in zip(names, tg, ref[8:]):
+        if r is None:
+            continue
+        assert np.abs(host(g) - r).max() < 2e-5 * max(np.abs(r).max(), 1e-30), k
