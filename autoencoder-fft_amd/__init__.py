@@ -297,7 +297,7 @@ class Context:
         self.check(self.L.aefft_backprop_spatial(self.h, _ptr(x), _ptr(out), _ptr(hin), _ptr(c), _ptr(b), _ptr(f), _ptr(p),
                                                  _ptr(dc), _ptr(db), _ptr(df), _ptr(dp), _ptr(ddc), _ptr(ddb), _ptr(ddf), _ptr(ddp),
                                                  B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, 1 if tied else 0,
-                                                 0 if semantics == "gpu" else 1))
+                                                 {"gpu": 0, "cpu": 1, "cuda_compat": 2}[semantics]))
 
     def set_flags(self, *names):
         """Development switches (include/aefft.h AEFFT_F_*), by name without the prefix; no names = defaults."""

@@ -783,7 +783,7 @@ extern "C" int aefft_update(aefft_ctx* ctx, float* c_d, float* f_d, float* b_d, 
 // spatial mode ------------------------------------------------------------------------------
 static void spatial_geom(int Nk, int Nl, int cpu_semantics, int* ak, int* al, int* lo)
 {
-    if (cpu_semantics) { *ak = (Nk - 1) / 2 - 1; *al = (Nl - 1) / 2 - 1; *lo = 1; }          // netlib.cpp:325-326,344
+    if (cpu_semantics == 1) { *ak = (Nk - 1) / 2 - 1; *al = (Nl - 1) / 2 - 1; *lo = 1; }     // netlib.cpp:325-326,344
     else { *ak = ((Nk - 1) / 2 - 1) / 2; *al = ((Nl - 1) / 2 - 1) / 2; *lo = 0; }             // backproplib.cu:123-124,95
 }
 
@@ -795,7 +795,7 @@ extern "C" int aefft_conv_spatial(aefft_ctx* ctx, const float* in_d, float* out_
     int ak, al, lo;
     spatial_geom(Nk, Nl, cpu_semantics, &ak, &al, &lo);
     Bracket br(ctx, KID_SPATIAL, ((double)B * (dD + dM) * Nx * Ny + (double)dM * dD * Nk * Nl) * 4.0);
-    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics ? 1.f : (float)dM, lo, ctx->stream);
+    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics == 1 ? 1.f : (float)dM, lo, ctx->stream);
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "conv_spatial", e);
     return AEFFT_OK;
 }
@@ -808,7 +808,7 @@ extern "C" int aefft_pool_conv_spatial(aefft_ctx* ctx, const float* in_d, float*
     int ak, al, lo;
     spatial_geom(Nk, Nl, cpu_semantics, &ak, &al, &lo);
     Bracket br(ctx, KID_SPATIAL, ((double)B * dD * Nx * Ny * scale * scale + (double)B * (dM + (pooled_d ? dD : 0)) * Nx * Ny + (double)dM * dD * Nk * Nl) * 4.0);
-    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics ? 1.f : (float)dM, lo, ctx->stream, scale, pooled_d);
+    hipError_t e = launch_conv_spatial(in_d, out_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, ak, al, cpu_semantics == 1 ? 1.f : (float)dM, lo, ctx->stream, scale, pooled_d);
     if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return fail(ctx, AEFFT_EINVAL, "aefft_pool_conv_spatial: kernel shape not served by the fused kernel"); }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "pool_conv_spatial", e);
     return AEFFT_OK;
@@ -855,6 +855,7 @@ extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const f
     {
         Bracket br(ctx, KID_SPATIAL, (double)B * (3.0 * dD + 2.0 * dM) * Nx * Ny * 4.0);
         hipError_t e = launch_spatial_grad(a, ctx->stream);
+        if (e == hipSuccess && cpu_semantics == 2) e = launch_spatial_compat(a, ctx->stream);      // Appendix B-11: bug-compatible gf, gb
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "spatial_grad", e);
     }
     UpdateArgs u{};

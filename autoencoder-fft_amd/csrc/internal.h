@@ -207,6 +207,7 @@ struct SpatialGradArgs {
     int tied;                             // backprop_gpu_cc: add the f-gradient into the c-gradient (backproplib.cu:466)
 };
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st);
+hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st);   // B-11: gf and gb as the CUDA source computes them (after launch_spatial_grad)
 size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl);
 hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale, hipStream_t st);   // netlib.cpp:114   // 0: shape not served by the tiled kernels
 

@@ -614,6 +614,80 @@ hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// SURVEY Appendix B-11 compat mode: the decoder-kernel and encoder-bias gradients exactly as the reference's CUDA source
+// computes them (oracle/np_spatial_literal.py, compat=True), overwriting what the kernels above produced:
+//   gf : gradient_CFBP reads the hidden layer at flat index (i-ik)*Nx + (j-il), gradient_CF at (i-ik)*Nx + (j-ik)
+//        (backproplib.cu:226,283: row stride Nx, column shifted by ik); an index outside the hin buffer is undefined
+//        behaviour there and reads 0 here; pixels whose shifted position is out of range keep the value of the PREVIOUS
+//        launch (the per-pixel buffer is written only inside the range test, :225,282; launches run in (m, d, k, l) order,
+//        the buffer starts zeroed per frame, :335).
+//   gb : `dDdB2 = ...` (:220) -- only the last d1 contributes.
+// Thread = one pixel of one frame walking all dM*dD*Nk*Nl launches in order with its buffer value in a register;
+// per launch the block sum goes to gf with one atomic per wave.  A reference-compat path, not a fast one.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spatial_compat_kernel(const SpatialGradArgs a)
+{
+    const long plane = (long)a.Nx * a.Ny;
+    const long px = (long)blockIdx.x * 256 + threadIdx.x;
+    const long bb = blockIdx.y;
+    const bool ok = px < plane;
+    const int i = ok ? (int)(px / a.Ny) : 0, j = ok ? (int)(px - (long)i * a.Ny) : 0;
+    const float* in = a.in + bb * a.dD * plane;
+    const float* out = a.out + bb * a.dD * plane;
+    const float* hin = a.hin + bb * a.dM * plane;
+    const long hsize = (long)a.dM * plane;
+    const float sc = 1.0f / a.Norm / (float)a.B;
+    float buf = 0.f;
+    for (int m = 0; m < a.dM; ++m)
+        for (int d = 0; d < a.dD; ++d) {
+            const float s0 = ok ? out[d * plane + px] - in[d * plane + px] : 0.f;
+            for (int k = 0; k < a.Nk; ++k) {
+                const int ik = -2 * a.ak - 1 + k;
+                for (int l = 0; l < a.Nl; ++l) {
+                    const int il = -2 * a.al - 1 + l;
+                    if (ok && i - ik >= 0 && i - ik < a.Nx && j - il >= 0 && j - il < a.Ny) {
+                        const long idx = (long)m * plane + (long)(i - ik) * a.Nx + ((k == 0 && l == 0) ? j - il : j - ik);
+                        buf = (idx >= 0 && idx < hsize) ? s0 * hin[idx] : 0.f;
+                    }
+                    float v = buf;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&a.gf[((d * a.dM + m) * a.Nk + k) * a.Nl + l], v * sc);
+                }
+            }
+        }
+    // gb[m] = sum_pixels s0[dD-1] * sum_{k1,l1 in range} f[dD-1][m][k1][l1]
+    const int dl = a.dD - 1;
+    const float s0 = ok ? out[dl * plane + px] - in[dl * plane + px] : 0.f;
+    for (int m = 0; m < a.dM; ++m) {
+        float w = 0.f;
+        for (int k1 = 0; k1 < a.Nk; ++k1) {
+            const int ik1 = -2 * a.ak - 1 + k1;
+            if (i - ik1 < 0 || i - ik1 >= a.Nx) continue;
+            for (int l1 = 0; l1 < a.Nl; ++l1) {
+                const int il1 = -2 * a.al - 1 + l1;
+                if (j - il1 >= 0 && j - il1 < a.Ny) w += a.f[((dl * a.dM + m) * a.Nk + k1) * a.Nl + l1];
+            }
+        }
+        float v = s0 * w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&a.gb[m], v * sc);
+    }
+}
+
+hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st)
+{
+    const size_t nk = (size_t)a.dM * a.dD * a.Nk * a.Nl;
+    hipError_t e = hipMemsetAsync(a.gf, 0, nk * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.gb, 0, a.dM * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    const long plane = (long)a.Nx * a.Ny;
+    spatial_compat_kernel<<<dim3((unsigned)((plane + 255) / 256), a.B), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
 {
     if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL)) {

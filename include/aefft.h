@@ -146,8 +146,11 @@ int aefft_pool_conv_spatial(aefft_ctx* ctx, const float* in_d, float* pooled_d, 
  *   d <- (1-alpha)*delmax*g/max(10,|g|) + alpha*d ; w <- w - d     (:392-396)
  * dc..dp are the caller's persistent previous-update buffers, ddc..ddp receive the gradients
  * (adapt_rate, :28-35, is otherwise inert -- Appendix B-12).  All device pointers; for B > 1 the
- * gradient is the mean over frames.  Gradient index/stale-buffer bugs of gradient_CF (Appendix
- * B-11) are NOT replicated: indices follow the CPU reference (netlib.cpp:425-430). */
+ * gradient is the mean over frames.  cpu_semantics: 0 = GPU geometry with the index / stale-buffer bugs of gradient_CF and the
+ * `dDdB2 =` of gradient_CFBP (Appendix B-11) following the CPU reference (netlib.cpp:425-430) -- the default; 1 = the CPU
+ * reference's geometry (ak = (Nk-1)/2-1, range test '>0'); 2 = GPU geometry WITH the B-11 bugs exactly as the CUDA source
+ * computes them (backproplib.cu:220,225-227,283; hidden-layer reads outside the buffer, undefined there, read 0): the
+ * "identical to the reference CUDA run" switch, slow. */
 int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
                            float* c_d, float* b_d, float* f_d, float* p_d,
                            float* dc_d, float* db_d, float* df_d, float* dp_d,

@@ -169,3 +169,27 @@ def test_backprop_gpu_many_bands(ctx, dD, dM, N, Nk, B, tied):
         if r is None:
             continue
         assert np.abs(host(g) - r).max() < 2e-5 * max(np.abs(r).max(), 1e-30), k
+
+
+@pytest.mark.parametrize("dD,dM,N,Nk", [(2, 2, 8, 3), (2, 3, 12, 5), (1, 2, 10, 3)])
+def test_b11_compat_switch_reproduces_the_cuda_source(ctx, dD, dM, N, Nk):
+    """semantics="cuda_compat" gives the decoder-kernel / encoder-bias gradients of the CUDA source as
+    written (hidden layer read at (i-ik)*Nx + (j-ik), stale per-pixel buffer, `dDdB2 =`), i.e. the literal restatement
+    oracle/np_spatial_literal.py with compat=True; the other two gradients are untouched."""
+    import np_spatial_literal as SL
+    rng = np.random.default_rng(dD + dM + N + Nk)
+    x = rng.uniform(0, 16, (1, dD, N, N)).astype(np.float32); out = (x + rng.uniform(-2, 2, x.shape)).astype(np.float32)
+    hin = rng.uniform(-4, 4, (1, dM, N, N)).astype(np.float32); f = rng.uniform(-1, 1, (dD, dM, Nk, Nk)).astype(np.float32)
+    z = np.zeros((dM, dD, Nk, Nk), np.float32)
+    res = {}
+    for sem in ("gpu", "cuda_compat"):
+        t = [ctx.dev(a) for a in (x, out, hin, z, np.zeros(dM), f, np.zeros(dD))]
+        tm = [ctx.dev(np.zeros_like(a)) for a in (z, np.zeros(dM), f, np.zeros(dD))]
+        tg = [ctx.dev(np.zeros_like(a)) for a in (z, np.zeros(dM), f, np.zeros(dD))]
+        ctx.backprop_spatial(*t, tm, tg, 0.0, 0.0, semantics=sem)
+        res[sem] = [host(g) for g in tg]                          # ddc, ddb, ddf, ddp
+    for sem, compat in (("gpu", False), ("cuda_compat", True)):
+        gc, gf, gb, gp = SL.gradients_literal(x[0], out[0], hin[0], f, compat=compat)
+        for got, ref, k in zip(res[sem], (gc, gb, gf, gp), ("gc", "gb", "gf", "gp")):
+            assert np.abs(got - ref).max() < 2e-5 * max(np.abs(ref).max(), 1e-30), (sem, k)
+    assert not np.allclose(res["gpu"][2], res["cuda_compat"][2])
