@@ -282,17 +282,18 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
     return AEFFT_OK;
 }
 
-static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, int ws_id = WS_MID)
+static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, int ws_id = WS_MID,
+                  const OpIn* opin = nullptr)
 {
     RET_IF(chk_size(ctx, Nx, Ny));
-    if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
+    if (!aligned16(x) || (!opin && !aligned16(X))) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
     void* mid;
     RET_IF(ws_get(ctx, ws_id, sizeof(float2) * fft_mid_elems(planes, Nx, Nyi / 2), &mid));
     const double b_in = (double)planes * bins(Nxi, Nyi) * 8, b_mid = (double)planes * Nx * (Nyi / 2) * 8, b_out = (double)planes * Nx * Ny * 4;
     hipError_t e;
     {
         Bracket br(ctx, KID_C2R_COLS, b_in + b_mid);
-        e = launch_c2r(X, nullptr, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->cur);
+        e = launch_c2r(X, nullptr, (float2*)mid, planes, Nxi, Nyi, Nx, Ny, scale, ctx->cur, opin);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r cols", e);
     {
@@ -1236,10 +1237,10 @@ static int launch_recon(aefft_net* n, float* recon_d, int wsid)
     const float2* src = q.O_stale ? q.Oc : q.O;
     const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
     if (n->op_state) {
-        Bracket br(ctx, KID_OPFORM, ((double)OPC * q.dD + 2.0 * n->B * q.dD) * bins(nxo, nyo) * 8.0);
-        hipError_t e = launch_recon_expand(src, n->Xf, n->Of, n->B, q.dD, q.Nx, q.Ny, nxo, nyo, ctx->cur);
-        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "recon_expand", e);
-        src = n->Of;
+        // operator form: O_0,b = O^_0 [x_b; 1] is evaluated inside the column pass of the inverse transform (no stored planes)
+        static_assert(OPIN_COLS == OPC, "operator width");
+        const OpIn op{src, n->Xf, q.dD, q.Nx, q.Ny};
+        return do_c2r(ctx, nullptr, recon_d, (long)n->B * q.dD, nxo, nyo, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid, &op);
     }
     return do_c2r(ctx, src, recon_d, (long)n->B * q.dD, nxo, nyo, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid);
 }
@@ -1278,16 +1279,18 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, n->ev_r2c, 0));
     } else RET_IF(do_r2c(ctx, frames_d, n->Xf, (long)BF * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
     n->pr[0].X = op ? n->A0hat : n->Xf;
-    if (op) {
-        Bracket br(ctx, KID_OPFORM, ((double)BF * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0);
+    // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
+    // hidden layers not materialised, decoder outputs on the coarsest grid's support
+    const bool chain_ok = op && lazy && n->Wp && (n->compact || L == 1) &&
+        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP));
+    const double mom_bytes = ((double)BF * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0;
+    if (op && !chain_ok) {
+        Bracket br(ctx, KID_OPFORM, mom_bytes);
         hipError_t e = launch_moment(n->Xf, n->Mhat, BF, n->D, n->pr[0].P, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "moment", e);
     }
-    // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
-    // hidden layers not materialised, decoder outputs on the coarsest grid's support
     bool chained = false;
-    if (op && lazy && n->Wp && (n->compact || L == 1) &&
-        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP))) {
+    if (chain_ok) {
         ChainArgs ca{};
         double bytes = 0;
         for (int l = 0; l < L; ++l) {
@@ -1299,7 +1302,8 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         }
         RET_IF(ensure_packed(n));
         ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
-        Bracket br(ctx, KID_OPFORM, bytes);
+        ca.mom_Xf = n->Xf; ca.mom_M = n->Mhat; ca.mom_B = BF;            // the batch moments share the launch
+        Bracket br(ctx, KID_OPFORM, bytes + mom_bytes);
         hipError_t e = launch_chain(ca, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
         chained = true;
@@ -1823,7 +1827,9 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         hipError_t e;
         {
             Bracket br(ctx, KID_KSPEC, kbytes);
-            e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+            const bool ride = n->op_state && n->Wp != nullptr;              // the bin-major copy for the next step's chain: same taps, same launch
+            e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr);
+            if (e == hipSuccess && ride) n->packed_valid = true;
         }
         if (e != hipSuccess) {
             if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kspec(group)", e);

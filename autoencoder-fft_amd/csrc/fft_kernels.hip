@@ -397,10 +397,30 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
     }
 }
 
+// Operator-form input of the reconstruction's inverse transform (opform_kernels.hip): the spectrum of plane (b, d) is not
+// stored but evaluated where it is read, O_b[d][t] = A[OPC-1][d][t] + sum_j A[j][d][t] x_b[j][u(t)] (u: the bin of the input grid
+// that bin t of this grid maps to) -- 4 loads and 3 complex FMAs per element instead of a launch that writes the planes out.
+__device__ __forceinline__ float2 opin_load(const OpIn& o, long plane, int t, int Nxi, int Nyi)
+{
+    const int b = (int)(plane / o.D0), d = (int)(plane - (long)b * o.D0);
+    const long Pc = (long)Nxi * (Nyi / 2 + 1), P0 = (long)o.Nx0 * (o.Ny0 / 2 + 1);
+    const unsigned nyr = Nyi / 2 + 1, NyrB = o.Ny0 / 2 + 1;
+    const unsigned i = (unsigned)t / nyr, j = (unsigned)t - i * nyr;
+    const unsigned bi = i < (unsigned)Nxi / 2 ? i : (i == (unsigned)Nxi / 2 ? (unsigned)o.Nx0 / 2 : i + o.Nx0 - Nxi);
+    const unsigned bj = j < nyr - 1 ? j : NyrB - 1;
+    const long u = (long)bi * NyrB + bj;
+    float2 acc = o.A[((long)(OPIN_COLS - 1) * o.D0 + d) * Pc + t];
+    for (int jj = 0; jj < o.D0; ++jj) {
+        const float2 a = o.A[((long)jj * o.D0 + d) * Pc + t], x = o.Xf[((long)b * o.D0 + jj) * P0 + u];
+        acc.x += a.x * x.x - a.y * x.y; acc.y += a.x * x.y + a.y * x.x;
+    }
+    return acc;
+}
+
 // inverse: in [planes][Nxi][Wc+1] (rows zero-padded to N) -> mid [planes][N][Wc], inverse FFT along x
 template <int N, int CW>
 __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __restrict__ in, float2* __restrict__ mid,
-                                                              int Wc, int Nxi)
+                                                              int Wc, int Nxi, const OpIn op)
 {
     constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
     extern __shared__ float2 s[];
@@ -411,26 +431,53 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
     const int c0 = blockIdx.y * CW;
     const int Nyri = Wc + 1;
     const float2* src = in + plane * Nxi * (long)Nyri;
+    auto ld = [&](long t) { return op.A ? opin_load(op, plane, (int)t, Nxi, 2 * Wc) : src[t]; };
 
-    for (int it = tid; it < N * CW; it += NT) {
-        const int r = it / CW, c = it % CW;
-        const int col = c0 + c;
-        const int sr = padsrc_row(r, N, Nxi);
-        float2 z = make_float2(0.f, 0.f);
-        if (col == 0) {
-            // Hermitian-symmetrise the two self-conjugate columns (imaginary parts of self-conjugate
-            // bins are thereby ignored) and pack them as DC + i*Nyquist
-            const int sm = padsrc_row((N - r) % N, N, Nxi);
-            float2 d0 = z, d1 = z, n0 = z, n1 = z;
-            if (sr >= 0) { d0 = src[(long)sr * Nyri]; n0 = src[(long)sr * Nyri + Wc]; }
-            if (sm >= 0) { d1 = src[(long)sm * Nyri]; n1 = src[(long)sm * Nyri + Wc]; }
+    // Only Nxi of the N rows carry data (the rest is the zero padding of the spectral up-sampling): zero the tile, then ALL loads
+    // of the Nxi x CW source elements in one batch (a rolled load -> store loop is one memory round trip per iteration), then the
+    // scatter to the padded rows.  The two self-conjugate columns of column 0 are parked in LDS and symmetrised afterwards.
+    float2* dcs = tws + N;                                          // [Nxi] column 0 (DC) and [Nxi] Nyquist column, when c0 == 0
+    float2* nys = dcs + Nxi;
+    if (Nxi < N) {
+        for (int it = tid; it < CW * PL; it += NT) s[it] = make_float2(0.f, 0.f);
+        __syncthreads();
+    }
+    constexpr int NLD = 8;                                          // = N * CW / NT
+    float2 v[NLD], w[NLD];
+    const int nsrc = Nxi * CW;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        if (k * NT < nsrc) {                                        // uniform
+            const int it = min(tid + k * NT, nsrc - 1);
+            const int sr = it / CW, c = it % CW;
+            v[k] = ld((long)sr * Nyri + c0 + c);
+            w[k] = (c0 + c == 0) ? ld((long)sr * Nyri + Wc) : make_float2(0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int it = tid + k * NT;
+        if (it < nsrc) {
+            const int sr = it / CW, c = it % CW;
+            if (c0 + c == 0) { dcs[sr] = v[k]; nys[sr] = w[k]; }
+            else {
+                const int r = Nxi == N ? sr : (sr < Nxi / 2 ? sr : (sr == Nxi / 2 ? N / 2 : sr + N - Nxi));    // inverse of padsrc_row
+                s[c * PL + pad_idx(r)] = v[k];
+            }
+        }
+    }
+    if (c0 == 0) {
+        __syncthreads();
+        for (int r = tid; r < N; r += NT) {
+            // Hermitian-symmetrise the two self-conjugate columns (imaginary parts of self-conjugate bins are thereby
+            // ignored) and pack them as DC + i*Nyquist
+            const int sr = padsrc_row(r, N, Nxi), sm = padsrc_row((N - r) % N, N, Nxi);
+            const float2 zz = make_float2(0.f, 0.f);
+            const float2 d0 = sr >= 0 ? dcs[sr] : zz, n0 = sr >= 0 ? nys[sr] : zz, d1 = sm >= 0 ? dcs[sm] : zz, n1 = sm >= 0 ? nys[sm] : zz;
             const float2 dc = make_float2(0.5f * (d0.x + d1.x), 0.5f * (d0.y - d1.y));
             const float2 ny = make_float2(0.5f * (n0.x + n1.x), 0.5f * (n0.y - n1.y));
-            z = make_float2(dc.x - ny.y, dc.y + ny.x);
-        } else if (sr >= 0) {
-            z = src[(long)sr * Nyri + col];
+            s[pad_idx(r)] = make_float2(dc.x - ny.y, dc.y + ny.x);
         }
-        s[c * PL + pad_idx(r)] = z;
     }
     __syncthreads();
     fft_lds<N, +1>(s + (tid / T) * PL, tid % T, tws);
@@ -482,24 +529,25 @@ template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float
     fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
     return hipGetLastError();
 }
-template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2* mid, long planes, int Wc, int Nxi, hipStream_t st)
+static OpIn g_opin_none{};
+template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2* mid, long planes, int Wc, int Nxi, hipStream_t st, const OpIn& op = g_opin_none)
 {
-    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N);
+    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N + 2 * Nxi);
     hipError_t e = allow_lds(inv_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
-    inv_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(in, mid, Wc, Nxi);
+    inv_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(in, mid, Wc, Nxi, op);
     return hipGetLastError();
 }
 
 // column tile width: at most 16, at most Wc, and CW*N/8 <= 1024 threads
-template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, float2* b, long planes, int Wc, int Nother, hipStream_t st)
+template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, float2* b, long planes, int Wc, int Nother, hipStream_t st, const OpIn& op = g_opin_none)
 {
     constexpr int CWMAX = (8192 / N) < 16 ? (8192 / N) : 16;
     int cw = CWMAX;
     while (cw > Wc) cw >>= 1;
 #define AEFFT_CW_CASE(C)                                                                                   \
     if constexpr (C <= CWMAX) {                                                                             \
-        if (cw == C) return FWD ? run_fwd_cols<N, C>(a, b, planes, Wc, Nother, st) : run_inv_cols<N, C>(a, b, planes, Wc, Nother, st); \
+        if (cw == C) return FWD ? run_fwd_cols<N, C>(a, b, planes, Wc, Nother, st) : run_inv_cols<N, C>(a, b, planes, Wc, Nother, st, op); \
     }
     AEFFT_CW_CASE(16) AEFFT_CW_CASE(8) AEFFT_CW_CASE(4)
 #undef AEFFT_CW_CASE
@@ -540,8 +588,9 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
 }
 
 // `in` non-null: run the column pass (in -> mid); `out` non-null: run the row pass (mid -> out).
-hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, hipStream_t st)
+hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, hipStream_t st, const OpIn* opin)
 {
+    const OpIn op = opin ? *opin : g_opin_none;
     if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxi > Nx || Nyi > Ny || Nyi < 8 || Nxi < 2 || (Nyi & 1) || (Nxi & 1))
         return hipErrorInvalidValue;
     if ((Nxi == Nx) != (Nyi == Ny)) return hipErrorInvalidValue;   // pad both axes or none
@@ -549,8 +598,8 @@ hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, in
     const int Wc = Nyi / 2;
     const long npairs = planes * Nx / 2;
     hipError_t e = hipSuccess;
-    if (in) {
-        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, false>(in, mid, planes, Wc, Nxi, st)); break)
+    if (in || op.A) {
+        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, false>(in, mid, planes, Wc, Nxi, st, op)); break)
         if (e != hipSuccess) return e;
     }
     if (out) {

@@ -25,8 +25,12 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
                       int Nxs, int Nys, hipStream_t st);
 // Batched 2-D C2R with optional fused spectral zero-pad (== `resize` up-sampling from
 // Nxi x Nyi, then cufftExecC2R, then * scale).  in [planes][Nxi][Nyi/2+1] -> out [planes][Nx][Ny].
+// opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
+// A[OPIN_COLS-1][d][t] + sum_{j<D0} A[j][d][t] * Xf[b][j][u(t)], A [OPIN_COLS][D0][Nxi*(Nyi/2+1)], Xf [B][D0][Nx0*(Ny0/2+1)]
+constexpr int OPIN_COLS = 4;
+struct OpIn { const float2* A; const float2* Xf; int D0, Nx0, Ny0; };
 hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi,
-                      int Nx, int Ny, float scale, hipStream_t st);
+                      int Nx, int Ny, float scale, hipStream_t st, const OpIn* opin = nullptr);
 size_t fft_mid_elems(long planes, int Nx, int Wc);   // complex elements needed in `mid`
 
 // ---- spectral_kernels.hip --------------------------------------------------------------
@@ -106,7 +110,8 @@ size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
 // The same transforms for up to 8 problems with equal (Nk, Nl) in ONE launch (kgrad: no row chunks, so no ksum pass).
 struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale; };
 struct PrunedGroup { PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8]; };
-hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
+struct PackArgs;
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed = nullptr /* the bin-major copy rides along as extra workgroups */);
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 // the inverse transform on a T x T support with T = 5 or 9 (the offsets kl + k'l' of 3x3 / 5x5 kernels, weight_kernels.hip)
 hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias = nullptr /* fused: the DC-bin terms as extra workgroups */);
@@ -163,12 +168,14 @@ struct ChainArgs {
     const float2* Wp; int E;   // bin-major copy of every matrix a coarsest-grid bin needs (kspec_packed_kernel)
     int tile_start[9];         // (filled by launch_chain) first workgroup of the planar tiles of grid j
     int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
+    const float2* mom_Xf; float2* mom_M; int mom_B;   // nullable: the batch moments M^ ride along as trailing workgroups (moment_body)
 };
 hipError_t launch_chain(ChainArgs& g, hipStream_t st);
 // Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps
 struct PackSeg { const float* k; int n, lev, off; };              // taps [n][Nk*Nk] of one tensor, its pair, its element offset in a record
 struct PackArgs { PackSeg seg[16]; int nseg, L, E, Nk; int Nx[8], Ny[8]; int NxC, NyC; long Pc; float2* Wp; const float2* tw;
-                  unsigned char blk_seg[128]; int blk_start[128]; /* (filled by the launcher) element blocks: tensor, first element */ };
+                  unsigned char blk_seg[128]; int blk_start[128]; int nblk; /* (pack_blocks) element blocks: tensor, first element */ };
+void pack_blocks(PackArgs& g);
 hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st);
 
 // ---- update_kernels.hip ----------------------------------------------------------------

@@ -14,35 +14,11 @@
 #include "../../include/aefft.h"
 #include "internal.h"
 #include "device_util.h"
+#include "opform_device.h"
 #include <algorithm>
 #include <type_traits>
 
 namespace aefft {
-
-// bin of the small grid [Nx][Ny/2+1] -> the bin of the big grid [NxB][NyB/2+1] it is cropped from / zero-padded to
-// (pool_fft's index map, fft_backproplib.cu:102-111 and 117-152; compositions of it have the same form)
-// (32-bit arithmetic: a plane has at most 2048 * 1025 bins, and 64-bit division costs hundreds of cycles)
-__device__ __forceinline__ long map_up(long s, int Nx, int Ny, int NxB, int NyB)
-{
-    const unsigned nyr = Ny / 2 + 1, NyrB = NyB / 2 + 1;
-    const unsigned i = (unsigned)s / nyr, j = (unsigned)s - i * nyr;
-    const unsigned bi = i < (unsigned)Nx / 2 ? i : (i == (unsigned)Nx / 2 ? (unsigned)NxB / 2 : i + NxB - Nx);
-    const unsigned bj = j < nyr - 1 ? j : NyrB - 1;
-    return (long)(bi * NyrB + bj);
-}
-// the bin of the small grid [Nxs][Nys/2+1] that lands on bin `bin` of the big grid [Nx][Ny/2+1], or -1 (crop_dest in 32 bits)
-__device__ __forceinline__ int crop_dest32(long bin, int Nx, int Ny, int Nxs, int Nys)
-{
-    const int Nyr = Ny / 2 + 1, Nyrs = Nys / 2 + 1;
-    const int i = (int)((unsigned)bin / (unsigned)Nyr), j = (int)((unsigned)bin - (unsigned)i * Nyr);
-    int di = -1, dj = -1;
-    if (i < Nxs / 2) di = i;
-    else if (i == Nx / 2) di = Nxs / 2;
-    else if (i > Nx - Nxs / 2) di = i - Nx + Nxs;
-    if (j < Nyrs - 1) dj = j;
-    else if (j == Nyr - 1) dj = Nyrs - 1;
-    return (di >= 0 && dj >= 0) ? di * Nyrs + dj : -1;
-}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
@@ -72,11 +48,10 @@ hipError_t launch_basis_fill(float2* A0, int D0, long P0, hipStream_t st)
 // second moments of the batch: M^[i][j][u] = sum_b x^_b[i][u] conj(x^_b[j][u]),  x^ = [x_0 .. x_{D0-1}, 0.., 1]
 // Workgroup = 64 bins x 4 frame slices; the slices are summed in slice order (deterministic).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moment_kernel(const float2* __restrict__ Xf, float2* __restrict__ M, int B, int D0, long P0)
+__device__ __forceinline__ void moment_body(const float2* __restrict__ Xf, float2* __restrict__ M, int B, int D0, long P0, long blk, int tx, int sl)
 {
     __shared__ float2 red[3][9][64];
-    const long u = (long)blockIdx.x * 64 + threadIdx.x;
-    const int sl = threadIdx.y;
+    const long u = blk * 64 + tx;
     const long uc = u < P0 ? u : P0 - 1;
     // upper triangle without the constant (3,3): (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3)
     float2 acc[9];
@@ -104,14 +79,14 @@ __global__ __launch_bounds__(256) void moment_kernel(const float2* __restrict__ 
     }
     if (sl > 0) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) red[sl - 1][e][threadIdx.x] = acc[e];
+        for (int e = 0; e < 9; ++e) red[sl - 1][e][tx] = acc[e];
     }
     __syncthreads();
     if (sl > 0 || u >= P0) return;
 #pragma unroll
     for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
-        for (int e = 0; e < 9; ++e) { const float2 v = red[s2][e][threadIdx.x]; acc[e].x += v.x; acc[e].y += v.y; }
+        for (int e = 0; e < 9; ++e) { const float2 v = red[s2][e][tx]; acc[e].x += v.x; acc[e].y += v.y; }
     const int ei[9] = {0, 0, 0, 0, 1, 1, 1, 2, 2}, ej[9] = {0, 1, 2, 3, 1, 2, 3, 2, 3};
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
@@ -121,6 +96,10 @@ __global__ __launch_bounds__(256) void moment_kernel(const float2* __restrict__ 
         if (ei[e] != ej[e]) M[(long)(ej[e] * OPC + ei[e]) * P0 + u] = make_float2(v.x, -v.y);
     }
     M[(long)(3 * OPC + 3) * P0 + u] = make_float2((float)B, 0.f);
+}
+__global__ __launch_bounds__(256) void moment_kernel(const float2* __restrict__ Xf, float2* __restrict__ M, int B, int D0, long P0)
+{
+    moment_body(Xf, M, B, D0, P0, blockIdx.x, threadIdx.x, threadIdx.y);
 }
 hipError_t launch_moment(const float2* Xf, float2* Mhat, int B, int D0, long P0, hipStream_t st)
 {
@@ -138,7 +117,7 @@ __global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
-    const OpPair& q = g.q[p];
+    const OpPair q = g.q[p];                                        // (by value: one bulk scalar load, not one per field use)
     const int dD = q.dD;
     const int rgroups = (dD + 3) / 4, bchunks = (dD + 7) / 8;
     int blk = blockIdx.x - g.start[p];
@@ -238,7 +217,7 @@ template <int BT>
 __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* sh)
 {
     constexpr int RT = 256 / BT;
-    const OpMsePair& q = g.q[p];
+    const OpMsePair q = g.q[p];                                     // (by value: one bulk scalar load)
     const int dD = q.dD, dM = q.dM;
     float2* As = sh;
     float2* Ts = sh + (size_t)OPC * dD * BT;
@@ -437,73 +416,21 @@ namespace aefft {
 // ------------------------------------------------------------------------------------------
 constexpr int CH_VMAX = 128, CH_WL = 6144;
 
-__device__ __forceinline__ float2 phase_tw(const float2* tw, int pos, int off, int N)
-{
-    // e^{-2 pi i pos*off / N}; N a power of two (pruned_kernels.hip `phase`)
-    return tw[((pos * off) & (N - 1)) * (TW_N / N)];
-}
+template <int NK> __global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g) { kspec_packed_body<NK>(g, blockIdx.x, blockIdx.y); }
 
-// Wp[t][e]: for support bin t the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 (chain order) at the bins of their grids that t
-// maps to.  Workgroup = 256 consecutive elements x TB support bins; thread = one element: its Nk*Nl taps stay in registers,
-// per bin the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} and then sum_k v_k e^{-2 pi i i kap_k / Nx}
-// (the association of kspec_body).  Stores are coalesced along e.
-template <int NK>
-__global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g)
+void pack_blocks(PackArgs& g)
 {
-    constexpr int TB = 8, KK = NK * NK;
-    __shared__ float2 ph[TB][2][NK];                               // [bin][row/col][tap] phases on this tensor's grid
-    __shared__ float taps[256 * KK];                               // the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
-    const PackSeg sd = g.seg[g.blk_seg[blockIdx.x]];               // (uniform: a workgroup's elements belong to ONE tensor)
-    const int l0 = g.blk_start[blockIdx.x];                        // first element of the block inside the tensor
-    const int nel = min(256, sd.n - l0);
-    const int t0 = blockIdx.y * TB;
-    for (int i = threadIdx.x; i < TB * 2 * NK; i += 256) {
-        const int k = i % NK, rc = (i / NK) & 1, b = i / (2 * NK);
-        const int t = min(t0 + b, (int)g.Pc - 1);
-        const long s = map_up(t, g.NxC, g.NyC, g.Nx[sd.lev], g.Ny[sd.lev]);
-        const int nyr = g.Ny[sd.lev] / 2 + 1;
-        const int bi = (int)((unsigned)s / (unsigned)nyr), bj = (int)((unsigned)s - (unsigned)bi * nyr);
-        ph[b][rc][k] = rc == 0 ? phase_tw(g.tw, bi, k - NK / 2, g.Nx[sd.lev]) : phase_tw(g.tw, bj, k - NK / 2, g.Ny[sd.lev]);
-    }
-    {
-        const float* src = sd.k + (long)l0 * KK;                   // nel * KK consecutive floats
-        const int nf = nel * KK;
-        float v[KK];                                               // every load of the copy in flight at once: one round trip
-#pragma unroll
-        for (int w = 0; w < KK; ++w) v[w] = src[min(w * 256 + (int)threadIdx.x, nf - 1)];
-#pragma unroll
-        for (int w = 0; w < KK; ++w) { const int f = w * 256 + threadIdx.x; if (f < nf) taps[f] = v[w]; }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x >= nel) return;
-    const int e = sd.off + l0 + threadIdx.x;
-    float c[NK * NK];
-#pragma unroll
-    for (int i = 0; i < NK * NK; ++i) c[i] = taps[threadIdx.x * KK + i];
-    for (int b = 0; b < TB && t0 + b < g.Pc; ++b) {
-        float2 cp[NK], rp[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { rp[k] = ph[b][0][k]; cp[k] = ph[b][1][k]; }
-        float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            float2 v = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int l = 0; l < NK; ++l) { v.x += c[k * NK + l] * cp[l].x; v.y += c[k * NK + l] * cp[l].y; }
-            acc.x += v.x * rp[k].x - v.y * rp[k].y;
-            acc.y += v.x * rp[k].y + v.y * rp[k].x;
-        }
-        g.Wp[(long)(t0 + b) * g.E + e] = acc;
-    }
+    int nb = 0;
+    for (int i = 0; i < g.nseg; ++i)
+        for (int l0 = 0; l0 < g.seg[i].n && nb < 128; l0 += 256) { g.blk_seg[nb] = (unsigned char)i; g.blk_start[nb] = l0; ++nb; }
+    g.nblk = nb;
 }
 
 hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 {
     if (g.nseg < 1 || g.nseg > 16 || g.L < 1 || g.L > 8 || g.E < 1 || (g.Nk != 3 && g.Nk != 5)) return hipErrorInvalidValue;
-    int nb = 0;
-    for (int i = 0; i < g.nseg; ++i)
-        for (int l0 = 0; l0 < g.seg[i].n; l0 += 256) { if (nb >= 128) return hipErrorInvalidValue; g.blk_seg[nb] = i; g.blk_start[nb] = l0; ++nb; }
-    const dim3 grid((unsigned)nb, (unsigned)((g.Pc + 7) / 8));
+    pack_blocks(g);
+    const dim3 grid((unsigned)g.nblk, (unsigned)((g.Pc + 7) / 8));
     if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, 0, st>>>(g);
     else kspec_packed_kernel<5><<<grid, 256, 0, st>>>(g);
     return hipGetLastError();
@@ -554,6 +481,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
     extern __shared__ float2 Wl[];                                   // planar tiles: two V tiles [rows][OPC][CH_BT]
     const int tid = threadIdx.x;
     const int L = g.L;
+    if ((int)blockIdx.x >= g.tile_start[L]) {
+        // trailing workgroups: the batch's second moments (independent of the chain: they share the launch)
+        moment_body(g.mom_Xf, g.mom_M, g.mom_B, g.D0, g.lv[0].P, (long)blockIdx.x - g.tile_start[L], tid & 63, tid >> 6);
+        return;
+    }
     if ((long)blockIdx.x < g.Pc) {
         __shared__ float2 V[2][CH_VMAX * OPC];
         const int t = blockIdx.x;
@@ -641,6 +573,7 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st)
     long total = g.Pc;
     for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
     g.tile_start[g.L] = (int)total;
+    if (g.mom_Xf) total += (g.lv[0].P + 63) / 64;
     if (total >= (1L << 31)) return hipErrorInvalidValue;
     int rmax = OPC;
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);

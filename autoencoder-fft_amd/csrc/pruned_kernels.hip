@@ -17,6 +17,7 @@
 // global twiddle table, so each bin costs one 8-byte global access plus LDS reads.
 #include "internal.h"
 #include "device_util.h"
+#include "opform_device.h"
 #include <algorithm>
 
 namespace aefft {
@@ -85,9 +86,17 @@ __global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ ke
 
 // all pairs' kernel spectra in one launch: problem p owns workgroups [start[p], start[p+1]), plane groups fastest
 template <int NK, int NL>
-__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw)
+__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk)
 {
     extern __shared__ float2 lds[];
+    if ((int)blockIdx.x >= g.start[g.n]) {
+        // trailing workgroups: the bin-major copy of the spectra for the operator chain (opform_device.h), from the same taps
+        if constexpr (NK == NL && (NK == 3 || NK == 5)) {
+            const int lin = blockIdx.x - g.start[g.n];
+            kspec_packed_body<NK>(pk, lin % pk.nblk, lin / pk.nblk);
+        }
+        return;
+    }
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
@@ -392,7 +401,8 @@ static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2
     return hipGetLastError();
 }
 
-template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st)
+static PackArgs g_pack_none{};
+template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st, PackArgs* pk = nullptr)
 {
     int total = 0; size_t lds = 0;
     long pb_all = 0;
@@ -410,7 +420,9 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     int threads = 256;                                    // one thread per (plane in group, column)
     for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
     if (threads > 320) return hipErrorInvalidValue;
-    kspec_group_kernel<NK, NL><<<dim3(total), threads, lds, st>>>(g, tw);
+    int extra = 0;
+    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * (int)((pk->Pc + 7) / 8); }
+    kspec_group_kernel<NK, NL><<<dim3(total + extra), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none);
     return hipGetLastError();
 }
 
@@ -489,11 +501,11 @@ hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed)
 {
     if (!pruned_group_ok(g, tw, Nk, Nl)) return hipErrorInvalidValue;
-    if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st);
-    if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st);
+    if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st, packed);
+    if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st, packed);
     return run_kspec_group<7, 7>(g, tw, st);
 }
 
