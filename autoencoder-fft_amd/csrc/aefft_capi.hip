@@ -20,7 +20,7 @@ enum { WS_MID = 0, WS_REAL = 1, WS_S = 2, WS_ES = 3, WS_E = 4, WS_DC = 5, WS_DF 
 // fine-grained kernel ids for profiling; the public classes (aefft.h) aggregate them
 enum {
     KID_R2C_ROWS = 0, KID_R2C_COLS, KID_C2R_COLS, KID_C2R_ROWS, KID_CONTRACT, KID_RESIZE, KID_DIFFMSE, KID_BIASGRAD,
-    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_WGRAD, KID_OPFORM, KID_COUNT
+    KID_PAD, KID_SHRINK, KID_UPDATE, KID_GDIFF, KID_SPATIAL, KID_KSPEC, KID_KGRAD, KID_WGRAD, KID_OPFORM, KID_CHAIN, KID_SGRAD, KID_OPMSE, KID_COUNT
 };
 
 struct ProfEvent { hipEvent_t a, b; int kid; double bytes; };
@@ -232,7 +232,7 @@ extern "C" int aefft_prof_reset(aefft_ctx* ctx)
 }
 
 static const char* kid_names[KID_COUNT] = {"r2c_rows", "r2c_cols", "c2r_cols", "c2r_rows", "contract", "resize", "diff_mse",
-                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad", "weight_taps", "opform"};
+                                           "bias_grad", "pad", "shrink", "update", "gradient_diff", "spatial", "kspec", "kgrad", "weight_taps", "moment", "chain", "sgrad", "opmse"};
 
 extern "C" int aefft_prof_read(aefft_ctx* ctx, int kid, long* launches, double* total_ms, double* algo_bytes)
 {
@@ -1303,7 +1303,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         RET_IF(ensure_packed(n));
         ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
         ca.mom_Xf = n->Xf; ca.mom_M = n->Mhat; ca.mom_B = BF;            // the batch moments share the launch
-        Bracket br(ctx, KID_OPFORM, bytes + mom_bytes);
+        Bracket br(ctx, KID_CHAIN, bytes + mom_bytes);
         hipError_t e = launch_chain(ca, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
         chained = true;
@@ -1643,7 +1643,7 @@ static int grads_grouped(aefft_net* n)
             bytes += ((double)OPC * q.dD * (q.P + bins(nxo, nyo)) + (double)OPC * OPC * q.P + (double)q.dD * q.dD * q.P) * 8.0;
         }
         sg.n = n->L; sg.Mhat = n->Mhat; sg.Nx0 = n->pr[0].Nx; sg.Ny0 = n->pr[0].Ny; sg.P0 = n->pr[0].P;
-        Bracket br(ctx, KID_OPFORM, bytes);
+        Bracket br(ctx, KID_SGRAD, bytes);
         hipError_t e = launch_sgrad_group(sg, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "sgrad", e);
     }
@@ -1826,7 +1826,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         hipError_t e;
         {
-            Bracket br(ctx, KID_KSPEC, kbytes);
+            Bracket br(ctx, KID_KSPEC, kbytes + ((n->op_state && n->Wp) ? (double)n->pack.Pc * n->pack.E * 8.0 : 0.0));
             const bool ride = n->op_state && n->Wp != nullptr;              // the bin-major copy for the next step's chain: same taps, same launch
             e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr);
             if (e == hipSuccess && ride) n->packed_valid = true;
@@ -1858,7 +1858,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         og.n = n->L; og.Mhat = n->Mhat; og.Nx0 = n->pr[0].Nx; og.Ny0 = n->pr[0].Ny; og.P0 = n->pr[0].P;
         {
-            Bracket br(ctx, KID_OPFORM, bytes);
+            Bracket br(ctx, KID_OPMSE, bytes);
             hipError_t e = launch_opmse_group(og, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "opmse", e);
         }

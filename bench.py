@@ -11,12 +11,20 @@ Default variant P2 = the reference's own pooling (New_Layer_Param.txt: scale 2 p
 
 One step = 1x autoenc_fft over the batch + for EVERY pair one backprop_fft loop-body iteration
 (gradient -> C2R -> shrink -> [all-reduce of the packed kernel-support gradients when N>1] ->
-update -> pad -> R2C -> re-forward of the pair -> MSE).  Nothing is skipped or cached.
+update -> pad -> R2C -> re-forward of the pair -> MSE), with these outputs produced every step: the
+reconstruction of every frame, the batch-mean gradients, the updated weights and kernel spectra, the
+post-update MSE of every pair.  What is NOT formed per frame: the network is linear (identity activation),
+so the step runs in OPERATOR FORM -- the per-bin operators of the layers on 4 basis
+frames, the batch's second moments, and small per-bin matrix products in place of the per-frame Hadamard
+products; intermediate feature maps are materialised only on request (aefft_net_get_layer[s]).  The same
+sums as the reference, batch contracted first; `--flags NOOPFORM` runs the per-frame form, and the parity
+tests run both against the oracle.
 
 Prints ONE JSON line (rank 0): metric/value per the driver contract, plus
   "roofline":     the dominant kernel's algorithmic bytes / its HIP-event-timed duration vs 8 TB/s
   "cpu_baseline": the reference's CPU path (oracle/_ref when built, else the C port) timed on this
                   host on a bounded sample (rank 0, N=1 only)
+  "variants":     short extra runs (rank 0, N=1 only): cfg3-P1 and a spatial-mode Conv+Conv+backprop step
 """
 import argparse
 import importlib
@@ -31,16 +39,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # kernel id (aefft_prof_name) -> kernel family in the rocprofv3 --pmc summaries under profiles/
-KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction, all instantiations of a step)"}
+KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction)", "r2c_rows": "r2c_rows_kernel<512> (input transform, row pass)",
+                "c2r_rows": "c2r_rows_kernel<512> (reconstruction, row pass)", "r2c_cols": "fwd_cols_kernel<512,16> (input transform, column pass + crop)",
+                "kgrad": "kgrad_group_kernel<9,9> (pruned inverse transform of S)", "opmse": "opmse_kernel (post-update MSE, operator form)",
+                "chain": "chain_kernel (network on the basis frames + batch moments)", "kspec": "kspec_group_kernel (kernel spectra from the taps)"}
 PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "contract_kernel", "contract_group_kernel"], "r2c_rows": ["r2c_rows_kernel"],
               "r2c_cols": ["fwd_cols_kernel"], "c2r_cols": ["inv_cols_kernel"], "c2r_rows": ["c2r_rows_kernel"],
-              "kgrad": ["kgrad_kernel", "kgrad_group_kernel"], "kspec": ["kspec_kernel", "kspec_group_kernel"], "diff_mse": ["diff_mse_kernel"]}
+              "kgrad": ["kgrad_kernel", "kgrad_group_kernel"], "kspec": ["kspec_kernel", "kspec_group_kernel"], "diff_mse": ["diff_mse_kernel"],
+              "opmse": ["opmse_kernel"], "chain": ["chain_kernel"], "sgrad": ["sgrad_kernel"], "moment": ["moment_kernel"], "weight_taps": ["wgrad_taps_kernel"]}
 
 
 def pmc_traffic(variant, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
-    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note; tools_pmc.py).  None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_cfg3{variant}.json")
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note; tools/pmc.py).  None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg3{variant}.json")
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -126,6 +138,69 @@ def cpu_baseline(N, scale, maps=(8, 16, 32, 64), D=3, Nk=5):
                                        "method": "EXTRAPOLATED, not timed: pair-1 time x iteration-count ratio of the backprop loop nest"}}
 
 
+def variant_p1(aefft, torch, np, ctx, steps=4):
+    """cfg3-P1 (no pooling: every pair at 512^2, 5.7 GB of kernel spectra -- honestly HBM-sized): a short timed run."""
+    N, D, maps, Nk, B = 512, 3, [8, 16, 32, 64], 5, 32
+    net = aefft.Net(ctx, D, N, N, maps, Nk, 1, batch=B)
+    init_weights(net, np)
+    dev = f"cuda:{ctx.device}"
+    frames = synth_frames(torch, B, D, N, dev, first_index=0)
+    recon = torch.empty_like(frames)
+    mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+    ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+    ctx.sync(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True); ctx.prof_reset()
+    net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+    prof = ctx.prof_read(); ctx.prof_enable(False)
+    ok = bool(np.isfinite(mse.cpu().numpy()).all())
+    net.close()
+    del frames, recon
+    torch.cuda.empty_cache()
+    step_bytes = sum(v["bytes"] for v in prof.values())
+    name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    return {"workload": "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512)", "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "mse_finite": ok, "step_algo_GB": step_bytes / 1e9, "step_frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            "dominant_kernel": {"name": name, "ms": dom["ms"], "GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] else 0.0}}
+
+
+def variant_spatial(aefft, torch, np, ctx, steps=5):
+    """Spatial mode (a13-a15): Conv_gpu -> Conv_gpu -> backprop_gpu on 32 frames 256x256x3, 50 maps, 3x3 (the reference's default
+    layer, New_Layer_Param.txt) -- flops roofline: 2*dM*dD*Nk*Nl*Nx*Ny per conv and per gradient correlation, fp32 matrix-core
+    peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The convs are bound by their 419 MB output / input streams, not by flops."""
+    B, dD, dM, N, Nk = 32, 3, 50, 256, 3
+    rng = np.random.default_rng(0)
+    x = ctx.dev(np.floor(rng.uniform(0, 256, (B, dD, N, N))))
+    c = ctx.dev(rng.uniform(-1, 1, (dM, dD, Nk, Nk))); b = ctx.dev(rng.uniform(-1, 1, dM))
+    f = ctx.dev(rng.uniform(-1, 1, (dD, dM, Nk, Nk))); p = ctx.dev(rng.uniform(-1, 1, dD))
+    mom = [torch.zeros_like(t) for t in (c, b, f, p)]
+    grads = [torch.zeros_like(t) for t in (c, b, f, p)]
+
+    def step():
+        h = ctx.conv_spatial(x, c, b)
+        o = ctx.conv_spatial(h, f, p)
+        ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
+
+    for _ in range(2):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    conv_flops = 2.0 * B * dM * dD * Nk * Nk * N * N
+    flops = 5 * conv_flops                     # 2 convs + back-conv + 2 gradient correlations
+    return {"workload": f"spatial mode: Conv_gpu+Conv_gpu+backprop_gpu, {B} frames {N}x{N}x{dD}, {dM} maps, {Nk}x{Nk}", "frames_per_s": B / dt,
+            "ms_per_step": dt * 1e3, "steps": steps, "algo_TFLOP_per_step": flops / 1e12,
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3}}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside a torch.distributed launcher: start the N ranks ourselves (one process per GPU) as a
     CHILD torch.distributed.run and pass its exit code on.  Nothing in this process has touched the GPU yet
@@ -183,7 +258,7 @@ def main():
     if a.prefetch or world > 1:
         # the synthetic frames are complete in HBM before the timed region: the next step's input R2C may run on a side stream.
         # Data-parallel runs wait for the gradient all-reduce between the two halves of a step; the prefetched R2C fills that gap
-        # together with this step's reconstruction inverse FFT (tools_gap.py: a 40 us gap then costs +11 us per step instead of +32;
+        # together with this step's reconstruction inverse FFT (tools/gap.py: a 40 us gap then costs +11 us per step instead of +32;
         # without a gap the mode costs +2 us, hence off at N = 1)
         net.set_input_ready(True)
     dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
@@ -244,13 +319,20 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(N, s if s > 1 else 2)
 
+    variants = None
+    if rank == 0 and world == 1 and not a.no_variants and a.variant == "p2" and a.size == 512:
+        net.close()
+        del frames, recon
+        torch.cuda.empty_cache()
+        variants = {"p1": variant_p1(aefft, torch, np, ctx), "spatial": variant_spatial(aefft, torch, np, ctx)}
+
     if rank == 0:
         out = {
             "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": world * B * a.steps / dt, "unit": "frames/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3-{a.variant.upper()}: {N}x{N}x3 frames, 4 pairs 3->8->16->32->64, 5x5, pool {s}/layer, FFT mode, "
-                                   f"fwd + 1 loop-body iteration per pair", "frames_per_gpu": B, "global_batch": world * B,
+                                   f"fwd + 1 loop-body iteration per pair ({'per-frame form' if 'NOOPFORM' in a.flags else 'operator form'})", "frames_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of packed kernel-support gradients)" if world > 1 else "")},
             "mse_per_pair": mse_host,
         }
@@ -258,6 +340,8 @@ def main():
             out["roofline"] = roof
         if cpu:
             out["cpu_baseline"] = cpu
+        if variants:
+            out["variants"] = variants
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
