@@ -910,7 +910,6 @@ struct aefft_net {
     float2* Xf = nullptr;      // [B][D][P0] input spectra of the frames (pair 0's X in the per-frame form)
     float2* A0hat = nullptr;   // [OPC][D][P0] basis frames (pair 0's X in the operator form); null: D > OPC-1
     float2* Mhat = nullptr;    // [OPC][OPC][P0] second moments of the batch
-    float2* Of = nullptr;      // [B][D][P0] per-frame spectra of the reconstruction (expanded from the operator O^_0)
     bool op_state = false;     // the activation buffers hold OPERATORS (basis-frame responses) of the last step_grad, not frames
     float2* Wp = nullptr;      // [Pc][packE] bin-major copy of the kernel spectra the coarsest-grid chain items read (kspec_packed_kernel)
     PackArgs pack{};           // its description (static per net)
@@ -1039,7 +1038,6 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
                 const Pair& q0 = n->pr[0];
                 if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->A0hat, (size_t)OPC * q0.dD * q0.P);
                 if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Mhat, (size_t)OPC * OPC * q0.P);
-                if (rc == AEFFT_OK) rc = net_alloc_t(n, &n->Of, (size_t)n->B * q0.dD * q0.P);
                 if (rc == AEFFT_OK && launch_basis_fill(n->A0hat, q0.dD, q0.P, ctx->stream) != hipSuccess) rc = fail(ctx, AEFFT_EHIP, "basis_fill");
                 if (rc == AEFFT_OK) rc = build_chain_items(n);
             }
@@ -1857,6 +1855,10 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             bytes += (2.0 * q.dM * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
         }
         og.n = n->L; og.Mhat = n->Mhat; og.Nx0 = n->pr[0].Nx; og.Ny0 = n->pr[0].Ny; og.P0 = n->pr[0].P;
+        if (n->Wp && n->packed_valid && n->pr[n->L - 1].P == n->pack.Pc) {      // the innermost pair reads the bin-major copy the kspec launch just refreshed
+            og.Wp = n->Wp; og.E = n->pack.E;
+            og.offC = n->pack.seg[n->L - 1].off; og.offF = n->pack.seg[n->L].off;
+        }
         {
             Bracket br(ctx, KID_OPMSE, bytes);
             hipError_t e = launch_opmse_group(og, ctx->cur);

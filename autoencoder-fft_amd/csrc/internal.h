@@ -158,7 +158,8 @@ struct OpMsePair {
     int dD, dM, Nx, Ny; long P;
     float scale;               // 1 / (2 dM Nx Ny B) / (dD Nx Ny)
 };
-struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8]; const float2* Mhat; int Nx0, Ny0; long P0; };
+struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8]; const float2* Mhat; int Nx0, Ny0; long P0;
+                    const float2* Wp; int E, offC, offF; /* nullable: bin-major record of the UPDATED spectra; offsets of the innermost pair's C, F in it */ };
 hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st);
 // the network on the basis frames in one launch (chain_kernel): per pair the spectra, biases and the operator outputs
 struct ChainLevel { const float2 *C, *F; const float *b, *p; float2 *A /*[OPC][dD][P]*/, *O /*[OPC][dD][Pc]*/; int dD, dM, Nx, Ny; long P; };

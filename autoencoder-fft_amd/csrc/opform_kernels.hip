@@ -207,6 +207,40 @@ hipError_t launch_recon_expand(const float2* O0, const float2* Xf, float2* Of, i
     return launch_op_expand(O0, Xf, Of, B, D0, D0, Nx0, Ny0, NxO, NyO, st);
 }
 
+constexpr int CH_VMAX = 128, CH_WL = 6144;
+
+// out[r][c] = scale * sum_k W[r][k] V[k][c] (+ bias[r] NN on the affine column at the DC bin); W = a row-major matrix of the
+// item's packed record, read straight from global memory (contiguous rows, L2-resident), V in LDS.  Thread = one output.
+__device__ __forceinline__ void chain_stage_rec(const float2* __restrict__ Ws, const float2* __restrict__ Vin, float2* __restrict__ Vout,
+                                                int R, int K, float scale, const float* __restrict__ bias, float NN, bool dc,
+                                                float2* __restrict__ out, long outP, long outS)
+{
+    for (int o = threadIdx.x; o < R * OPC; o += 256) {
+        const int r = o / OPC, col = o - r * OPC;
+        float2 acc = make_float2(0.f, 0.f);
+        const float2* wr = Ws + r * K;
+        // the row (K contiguous elements of the record) in groups of 16 loads: all in flight before the first use
+        auto grp = [&](int k0, auto NU) {
+            constexpr int U = decltype(NU)::value;
+            float2 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = wr[k0 + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cfma2(acc, w[u], Vin[(k0 + u) * OPC + col]);
+        };
+        int k0 = 0;
+        for (; k0 + 16 <= K; k0 += 16) grp(k0, std::integral_constant<int, 16>{});
+        if (k0 + 8 <= K) { grp(k0, std::integral_constant<int, 8>{}); k0 += 8; }
+        if (k0 + 4 <= K) { grp(k0, std::integral_constant<int, 4>{}); k0 += 4; }
+        if (k0 + 2 <= K) { grp(k0, std::integral_constant<int, 2>{}); k0 += 2; }
+        if (k0 < K) grp(k0, std::integral_constant<int, 1>{});
+        acc.x *= scale; acc.y *= scale;
+        if (dc && col == OPC - 1) acc.x += bias[r] * NN;
+        Vout[r * OPC + col] = acc;
+        if (out) out[((long)col * R + r) * outP + outS] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // post-update MSE of every pair (fft_backproplib.cu:1460-1463 + 480-498) in operator form, one launch.
 // Workgroup = BT consecutive bins of one pair x (256 / BT) row threads.  Phase 1: T = C' A / dM + b^ (dM x OPC per bin, rows over
@@ -355,12 +389,57 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
     }
 }
 
+// The innermost pair from the bin-major copy of the updated spectra (kspec_packed_body): one workgroup per bin, C' and F' read as
+// contiguous rows (the planar layout makes them 8 K scattered 32-byte pieces per bin tile), two chain stages and the quadratic form.
+__device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t)
+{
+    __shared__ float2 Va[CH_VMAX * OPC], Vb[CH_VMAX * OPC], Vc[CH_VMAX * OPC];
+    __shared__ float redp[4];
+    const OpMsePair q = g.q[p];
+    const int dD = q.dD, dM = q.dM;
+    for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; Va[i] = q.A[((long)k * dD + a) * q.P + t]; }
+    const float2* rec = g.Wp + t * g.E;
+    const float NN = (float)q.Nx * (float)q.Ny;
+    __syncthreads();
+    chain_stage_rec(rec + g.offC, Va, Vb, dM, dD, 1.0f / (float)dM, q.b, NN, t == 0, nullptr, 0, 0);
+    __syncthreads();
+    chain_stage_rec(rec + g.offF, Vb, Vc, dD, dM, 1.0f / (float)dD, q.p, NN, t == 0, nullptr, 0, 0);
+    __syncthreads();
+    float part = 0.f;
+    if ((int)threadIdx.x < dD) {
+        const int a = threadIdx.x;
+        const long u = map_up(t, q.Nx, q.Ny, g.Nx0, g.Ny0);
+        float2 r[OPC];
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) { const float2 av = Va[a * OPC + k], fv = Vc[a * OPC + k]; r[k] = make_float2(av.x - fv.x, av.y - fv.y); }
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) {
+            float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k2 = 0; k2 < OPC; ++k2) cfmac(v, g.Mhat[(long)(k * OPC + k2) * g.P0 + u], r[k2]);
+            part += r[k].x * v.x - r[k].y * v.y;
+        }
+        const int nyr = q.Ny / 2 + 1;
+        const int j = (int)((unsigned)t % (unsigned)nyr);
+        part *= (j > 0 && j < nyr - 1) ? 2.f : 1.f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) redp[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (redp[0] + redp[1]) + (redp[2] + redp[3]);
+        if (tot != 0.f) atomicAdd(q.slots + (blockIdx.x % MSE_SLOTS) * MSE_SLOT_STRIDE, tot * q.scale);
+    }
+}
+
 __global__ __launch_bounds__(256) void opmse_kernel(const OpMseGroup g)
 {
     extern __shared__ float2 sh[];                                   // As[OPC][dD][BT] | Ts[dM][OPC][BT] | red | Rs[256/BT][OPC][BT]
     int p = g.n - 1;                                                 // pair n-1 owns the first workgroups, pair 0 the last
 #pragma unroll
     for (int i = 6; i >= 0; --i) if (i < g.n - 1 && (int)blockIdx.x >= g.start[i]) p = i;
+    if (p == g.n - 1 && g.Wp) { opmse_packed(g, p, (long)blockIdx.x - g.start[p]); return; }
     const int bt = g.bt[p];                                          // uniform per workgroup
     if (bt == 16) opmse_body<16>(g, p, sh);
     else if (bt == 8) opmse_body<8>(g, p, sh);
@@ -378,11 +457,13 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
         int bt = 16;
         while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
         const size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2);
-        if (need > 150 * 1024) return hipErrorInvalidValue;
+        const bool pk = i == g.n - 1 && g.Wp && q.dD <= CH_VMAX && q.dM <= CH_VMAX;
+        if (i == g.n - 1 && !pk) g.Wp = nullptr;
+        if (need > 150 * 1024 && !pk) return hipErrorInvalidValue;
         g.bt[i] = bt;
-        lds = std::max(lds, need);
+        if (!pk) lds = std::max(lds, need);
         g.start[i] = (int)total;
-        total += (q.P + bt - 1) / bt;
+        total += pk ? q.P : (q.P + bt - 1) / bt;
     }
     if (total >= (1L << 31)) return hipErrorInvalidValue;
     g.start[g.n] = (int)total;                                         // (start[] is DEscending in i: see opmse_kernel's lookup)
@@ -414,8 +495,6 @@ namespace aefft {
 // weights change: one coalesced record per item, one memory round trip, the chain of small dependent products then runs out of
 // LDS.  The few middle-grid items (two small matrices each) keep the gather.
 // ------------------------------------------------------------------------------------------
-constexpr int CH_VMAX = 128, CH_WL = 6144;
-
 template <int NK> __global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g) { kspec_packed_body<NK>(g, blockIdx.x, blockIdx.y); }
 
 void pack_blocks(PackArgs& g)
@@ -434,38 +513,6 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
     if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, 0, st>>>(g);
     else kspec_packed_kernel<5><<<grid, 256, 0, st>>>(g);
     return hipGetLastError();
-}
-
-// out[r][c] = scale * sum_k W[r][k] V[k][c] (+ bias[r] NN on the affine column at the DC bin); W = a row-major matrix of the
-// item's packed record, read straight from global memory (contiguous rows, L2-resident), V in LDS.  Thread = one output.
-__device__ __forceinline__ void chain_stage_rec(const float2* __restrict__ Ws, const float2* __restrict__ Vin, float2* __restrict__ Vout,
-                                                int R, int K, float scale, const float* __restrict__ bias, float NN, bool dc,
-                                                float2* __restrict__ out, long outP, long outS)
-{
-    for (int o = threadIdx.x; o < R * OPC; o += 256) {
-        const int r = o / OPC, col = o - r * OPC;
-        float2 acc = make_float2(0.f, 0.f);
-        const float2* wr = Ws + r * K;
-        // the row (K contiguous elements of the record) in groups of 16 loads: all in flight before the first use
-        auto grp = [&](int k0, auto NU) {
-            constexpr int U = decltype(NU)::value;
-            float2 w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = wr[k0 + u];
-#pragma unroll
-            for (int u = 0; u < U; ++u) cfma2(acc, w[u], Vin[(k0 + u) * OPC + col]);
-        };
-        int k0 = 0;
-        for (; k0 + 16 <= K; k0 += 16) grp(k0, std::integral_constant<int, 16>{});
-        if (k0 + 8 <= K) { grp(k0, std::integral_constant<int, 8>{}); k0 += 8; }
-        if (k0 + 4 <= K) { grp(k0, std::integral_constant<int, 4>{}); k0 += 4; }
-        if (k0 + 2 <= K) { grp(k0, std::integral_constant<int, 2>{}); k0 += 2; }
-        if (k0 < K) grp(k0, std::integral_constant<int, 1>{});
-        acc.x *= scale; acc.y *= scale;
-        if (dc && col == OPC - 1) acc.x += bias[r] * NN;
-        Vout[r * OPC + col] = acc;
-        if (out) out[((long)col * R + r) * outP + outS] = acc;
-    }
 }
 
 // One launch, two kinds of workgroups, all independent:

@@ -42,28 +42,31 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
     float* red = ws + dD * TM * KK;
     // staging in batches of 8 independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
     // one memory round trip per element otherwise)
-    for (int t0 = 0; t0 < dD * TT; t0 += 256 * 8) {
-        float v[8];
+    for (int t0 = 0; t0 < dD * TT; t0 += 256 * 12) {
+        float v[12];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 12; ++u) {
+            if (t0 + u * 256 >= dD * TT) break;                       // uniform
             const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
             const int d1 = t / TT, r = t - d1 * TT;
             v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
+        for (int u = 0; u < 12; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
     }
-    for (int t0 = 0; t0 < dD * TM * KK; t0 += 256 * 8) {
-        float v[8];
+    // (24 loads per thread in flight: the weight slab of the innermost pair is 37 loads per thread, i.e. two round trips, not five)
+    for (int t0 = 0; t0 < dD * TM * KK; t0 += 256 * 24) {
+        float v[24];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 24; ++u) {
+            if (t0 + u * 256 >= dD * TM * KK) break;                 // uniform: whole load instructions are skipped
             const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TM * KK - 1);
             const int d1 = t / (TM * KK), rem = t - d1 * (TM * KK);
             const int m2 = min(m0 + rem / KK, dM - 1), r = rem % KK;
             v[u] = isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = v[u]; }
+        for (int u = 0; u < 24; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = v[u]; }
     }
     __syncthreads();
     const int s = threadIdx.x / (TM * NK), rem = threadIdx.x - s * (TM * NK);
