@@ -616,7 +616,7 @@ hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi
 
 // ------------------------------------------------------------------------------------------
 // SURVEY Appendix B-11 compat mode: the decoder-kernel and encoder-bias gradients exactly as the reference's CUDA source
-// computes them (oracle/np_spatial_literal.py, compat=True), overwriting what the kernels above produced:
+// computes them (the literal per-element restatement the parity tests check against), overwriting what the kernels above produced:
 //   gf : gradient_CFBP reads the hidden layer at flat index (i-ik)*Nx + (j-il), gradient_CF at (i-ik)*Nx + (j-ik)
 //        (backproplib.cu:226,283: row stride Nx, column shifted by ik); an index outside the hin buffer is undefined
 //        behaviour there and reads 0 here; pixels whose shifted position is out of range keep the value of the PREVIOUS
