@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOGRAPH", AEFFT_F_NOGRAPH}, {"NOCHAIN", AEFFT_F_NOCHAIN}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}};
 static void flags_from_env_once()
 {
     static bool done = false;

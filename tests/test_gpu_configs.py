@@ -126,7 +126,7 @@ def test_config5_full_size_runs(ctx):
     net.close()
 
 
-LITERAL = ["NOOPFORM", "NOGRAPH", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
+LITERAL = ["NOOPFORM", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
 
 
 @pytest.mark.gpu

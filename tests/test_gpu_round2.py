@@ -13,7 +13,7 @@ from test_gpu_fft_path import _pair, _step_vs_oracle, host, relerr
 pytestmark = pytest.mark.gpu
 aefft = importlib.import_module("autoencoder-fft_amd")
 
-LITERAL = ["NOOPFORM", "NOGRAPH", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
+LITERAL = ["NOOPFORM", "NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP"]
 
 
 @pytest.fixture(scope="module")
