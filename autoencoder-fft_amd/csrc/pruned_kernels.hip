@@ -428,9 +428,8 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
 
 template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st, BiasGradGroup* bgp = nullptr)
 {
-    // 512 threads: the per-thread row sums live in LDS ([2][NK][NT+1] floats = 37 KB for the 9x9 offsets), and with 1024 threads
-    // only two workgroups fit a CU -- the ~600 workgroups of a cfg3 step then need a second, mostly empty, round
-    constexpr int NT = 512;
+    // (512-thread workgroups were tried: 32.5 us against 30.1 us -- the few big planes of pair 0 are the long pole, not residency)
+    constexpr int NT = 1024;
     int total = 0; size_t lds = 0;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];

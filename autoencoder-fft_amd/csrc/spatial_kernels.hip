@@ -454,6 +454,254 @@ static hipError_t run_wcorr(const WCorrArgs& a, int B, float* out, float* osum, 
     wsum_kernel<TA, TB, NK><<<dim3((total + 3) / 4), 256, 0, st>>>(a.part, out, osum, a.nA, a.nB, bands * B, scale);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------------------------------
+// mcorr_kernel<NK,NCB>: the same weight-gradient correlations as ONE GEMM per launch on the matrix cores (32x32x2 f32):
+//     out[row a][col (b,k,l)] = sum_{frames, pixels} A[a][pix] * Bv[b][pix shifted by sgn*tap]      M = planes of A, N = nB*NK*NK, K = pixels
+// Rows are the UNSHIFTED planes (always the side with the many channels: the back-convolved error g for dC, the hidden layer for
+// dF after re-indexing the sum by i' = i - ik), columns the shifted copies of the few planes of the other side -- gathered per lane
+// from an LDS tile with halo, so nothing is materialised.  One extra column of ones gives the row sums (dB), one extra row of ones
+// the column sums at the zero-shift tap (dP).  A workgroup owns a 16-row band of one frame (x 64 rows x 32*NCB columns of the
+// GEMM) and walks it in chunks of 2 image rows x 64 columns: the A tile [64][128 px] goes through LDS, every wave takes a quarter of the chunk's pixels = 16 k-steps of 2*NCB MFMAs.
+// The global loads of the next TWO chunks are in flight while the current one is multiplied (two register sets).  Partials [workgroup][64][32*NCB] are summed
+// in a fixed order by msum_kernel.
+// ------------------------------------------------------------------------------------------
+struct MCorrArgs {
+    const float* A; int nA, loA;            // rows   [B][nA][Nx][Ny]; pixels with i < loA or j < loA count as 0
+    const float *Bp, *Bp2; int nB, loB;     // columns: (Bp - Bp2)[B][nB][Nx][Ny] read at (i + sgn*(ik0+k), j + sgn*(il0+l)), 0 outside [loB, N)
+    int sgn, Nx, Ny, ik0, il0;
+    int ones_row, ones_col;                 // append a row / a column of ones
+    int row0, col0;                         // first GEMM row / column of this launch's tile (multiples of 64 / 32*NCB)
+    float* part;                            // [B * bands][64][32*NCB]
+};
+
+template <int NK, int NCB>
+__global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
+{
+    constexpr int KK = NK * NK, CR = 2, CC = 64, CPX = CR * CC, PA = CPX + 4;          // chunk: 2 rows x 64 columns; A tile pitch (16-byte rows)
+    constexpr int TWR = CR + NK - 1, TWC = CC + NK - 1, TB = 3;                         // B tile with halo; at most 3 planes staged at a time
+    __shared__ __attribute__((aligned(16))) float At[64 * PA];
+    __shared__ float Bt[TB][TWR * TWC];
+    const int band = blockIdx.x;
+    const long bb = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, kq = lane >> 5;
+    const long plane = (long)a.Nx * a.Ny;
+    // per column block: which plane / tap this lane's column is, and its offset inside the B tile
+    int cplane[NCB], coff[NCB];
+    float cone[NCB];
+    const int ncol = a.nB * KK;
+    int pmin = 1 << 30, pmax = -1;                                                        // (uniform bounds of the planes this launch touches)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int col = a.col0 + 32 * cb + li;
+        cone[cb] = (a.ones_col && col == ncol) ? 1.f : 0.f;
+        if (col < ncol) {
+            const int b = col / KK, kl = col - b * KK, k = kl / NK, l = kl - k * NK;
+            cplane[cb] = b;
+            // image index = pixel + sgn*(ik0 + k); tile origin = chunk origin + min shift
+            const int sr = a.sgn * (a.ik0 + k), sc = a.sgn * (a.il0 + l);
+            const int r0s = a.sgn > 0 ? a.ik0 : -(a.ik0 + NK - 1), c0s = a.sgn > 0 ? a.il0 : -(a.il0 + NK - 1);
+            coff[cb] = (sr - r0s) * TWC + (sc - c0s);
+        } else { cplane[cb] = -1; coff[cb] = 0; }
+    }
+    {
+        const int c_lo = a.col0, c_hi = min(a.col0 + 32 * NCB, ncol) - 1;
+        pmin = c_lo / KK; pmax = c_hi >= c_lo ? c_hi / KK : pmin;         // (a tile holding only the ones column still makes one pass)
+    }
+    const int r0s = a.sgn > 0 ? a.ik0 : -(a.ik0 + NK - 1), c0s = a.sgn > 0 ? a.il0 : -(a.il0 + NK - 1);
+    v16f_s acc[2][NCB];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
+    constexpr int BR = 8;                                             // image rows per workgroup (band)
+    const int nchunk_c = (a.Ny + CC - 1) / CC, nchunks = (BR / CR) * nchunk_c;
+    constexpr int NBL = (TB * TWR * TWC + 255) / 256;
+    // loads of a chunk: the A tile (64 planes x 128 px = 2048 float4, 8 per thread) and the B tiles of one plane group
+    // (raw, branch-free loads from clamped addresses: every range test and mask is applied when the registers go to LDS -- a test
+    //  on the loaded value right after the load would make each load wait for the one before it)
+    auto load_A = [&](int ch, float4 (&av)[8]) {
+        const int i0 = band * BR + (ch / nchunk_c) * CR, j0 = (ch % nchunk_c) * CC;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int t = w * 256 + threadIdx.x;
+            const int row = t / (CPX / 4), q = (t % (CPX / 4)) * 4;              // GEMM row, pixel quad inside the chunk
+            const int i = min(i0 + q / CC, a.Nx - 1), j = min(j0 + q % CC, a.Ny - 4);
+            const int ga = min(a.row0 + row, a.nA - 1);
+            av[w] = *reinterpret_cast<const float4*>(a.A + (bb * a.nA + ga) * plane + (long)i * a.Ny + j);
+        }
+    };
+    auto store_A = [&](int ch, const float4 (&av)[8]) {
+        const int i0 = band * BR + (ch / nchunk_c) * CR, j0 = (ch % nchunk_c) * CC;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int t = w * 256 + threadIdx.x;
+            const int row = t / (CPX / 4), q = (t % (CPX / 4)) * 4;
+            const int i = i0 + q / CC, j = j0 + q % CC;
+            const int ga = a.row0 + row;
+            const bool ones = a.ones_row && ga == a.nA;
+            const float vv[4] = {av[w].x, av[w].y, av[w].z, av[w].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in_img = i < a.Nx && j + e < a.Ny;
+                float x = (ga < a.nA && in_img && i >= a.loA && j + e >= a.loA) ? vv[e] : 0.f;
+                if (ones && in_img) x = 1.f;
+                o[e] = x;
+            }
+            // one 16-byte write per lane (consecutive lanes -> consecutive quads of a row: conflict-free); the MFMA's A-operand reads
+            // of 32 rows at one pixel are 4-way conflicted with this pitch, which costs a few cycles beside 128 cycles of MFMA
+            *reinterpret_cast<float4*>(At + row * PA + q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    auto load_B = [&](int ch, int p0, float (&bvr)[NBL], float (&bvr2)[NBL]) {
+        const int i0 = band * BR + (ch / nchunk_c) * CR, j0 = (ch % nchunk_c) * CC;
+#pragma unroll
+        for (int w = 0; w < NBL; ++w) {
+            const int t = min(w * 256 + (int)threadIdx.x, TB * TWR * TWC - 1);
+            const int u = t / (TWR * TWC), q = t - u * (TWR * TWC);
+            const int b = min(p0 + u, a.nB - 1);
+            const int r = min(max(i0 + r0s + q / TWC, 0), a.Nx - 1), c = min(max(j0 + c0s + q % TWC, 0), a.Ny - 1);
+            const long idx = (bb * a.nB + b) * plane + (long)r * a.Ny + c;
+            bvr[w] = a.Bp[idx];
+            bvr2[w] = a.Bp2 ? a.Bp2[idx] : 0.f;
+        }
+    };
+    auto store_B = [&](int ch, int p0, const float (&bvr)[NBL], const float (&bvr2)[NBL]) {
+        const int i0 = band * BR + (ch / nchunk_c) * CR, j0 = (ch % nchunk_c) * CC;
+#pragma unroll
+        for (int w = 0; w < NBL; ++w) {
+            const int t = w * 256 + threadIdx.x;
+            if (t < TB * TWR * TWC) {
+                const int u = t / (TWR * TWC), q = t - u * (TWR * TWC);
+                const int b = p0 + u;
+                const int r = i0 + r0s + q / TWC, c = j0 + c0s + q % TWC;
+                const bool ok = b <= pmax && b < a.nB && r >= a.loB && r < a.Nx && c >= a.loB && c < a.Ny;
+                Bt[u][q] = ok ? bvr[w] - bvr2[w] : 0.f;
+            }
+        }
+    };
+    const bool one_group = pmax - pmin < TB;                          // (uniform) the usual case: all B planes staged at once, prefetched with A
+    // one chunk: tiles from the register set -> LDS, the loads of chunk ch + 2 into the same set (two chunks in flight), the MFMAs
+    auto step = [&](int ch, float4 (&av)[8], float (&bvr)[NBL], float (&bvr2)[NBL]) {
+        __syncthreads();                                             // the previous chunk's MFMAs are done with the tiles
+        store_A(ch, av);
+        if (one_group) store_B(ch, pmin, bvr, bvr2);
+        if (ch + 2 < nchunks) { load_A(ch + 2, av); if (one_group) load_B(ch + 2, pmin, bvr, bvr2); }
+        for (int p0 = pmin; p0 <= pmax; p0 += TB) {
+            if (!one_group) {
+                if (p0 > pmin) __syncthreads();
+                float tmp[NBL], tmp2[NBL];
+                load_B(ch, p0, tmp, tmp2);
+                store_B(ch, p0, tmp, tmp2);
+            }
+            __syncthreads();
+            // wave wv: pixels [32 wv, 32 wv + 32) of the chunk, 2 per k-step
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                const int px = 32 * wv + 2 * ks + kq;
+                const int pr = px / CC, pc = px - pr * CC;
+                const float a0 = At[li * PA + px], a1 = At[(32 + li) * PA + px];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int u = cplane[cb] - p0;
+                    float bvv = 0.f;
+                    if (cplane[cb] >= 0) { if (u >= 0 && u < TB) bvv = Bt[u][coff[cb] + pr * TWC + pc]; }
+                    else if (p0 == pmin) bvv = cone[cb];                 // the ones column counts once, with the first plane group
+                    acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bvv, acc[0][cb], 0, 0, 0);
+                    acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[1][cb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    float4 av0[8], av1[8];
+    float bv0[NBL], bv1[NBL], bw0[NBL], bw1[NBL];
+    load_A(0, av0);
+    if (one_group) load_B(0, pmin, bv0, bw0);
+    if (nchunks > 1) { load_A(1, av1); if (one_group) load_B(1, pmin, bv1, bw1); }
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        step(ch, av0, bv0, bw0);
+        if (ch + 1 < nchunks) step(ch + 1, av1, bv1, bw1);
+    }
+    // the four waves' accumulators -> one partial tile, summed in wave order through LDS (At is free now)
+    __syncthreads();
+    float* red = At;                                                  // [64][32] per column block at a time
+    float* dst = a.part + ((bb * gridDim.x + band) * 64) * (long)(32 * NCB);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        for (int w2 = 0; w2 < 4; ++w2) {
+            if (wv == w2) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kq;
+                        float* q = red + row * 33 + li;
+                        *q = w2 == 0 ? acc[rb][cb][e] : *q + acc[rb][cb][e];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int t = threadIdx.x; t < 64 * 32; t += 256) dst[(long)(t >> 5) * (32 * NCB) + 32 * cb + (t & 31)] = red[(t >> 5) * 33 + (t & 31)];
+        __syncthreads();
+    }
+}
+
+// out = scale * sum over workgroups of part[.][row][col] for the rows / columns of this tile; transposed scatter for dF
+__global__ __launch_bounds__(256) void msum_kernel(const float* __restrict__ part, int nparts, int ncols_tile, int row0, int col0,
+                                                   int nA, int ncol, int KK, int nB, int transpose, float* __restrict__ out,
+                                                   float* __restrict__ row_sums, float* __restrict__ col_sums, int zero_tap, float scale)
+{
+    // one wave per element of the 64 x ncols_tile tile
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= 64 * ncols_tile) return;
+    const int row = e / ncols_tile, colt = e - row * ncols_tile;
+    const int ga = row0 + row, col = col0 + colt;
+    const bool is_w = ga < nA && col < ncol, is_rs = ga < nA && col == ncol && row_sums, is_cs = ga == nA && col < ncol && col_sums;
+    if (!is_w && !is_rs && !is_cs) return;
+    float s = 0.f;
+    for (int p = lane; p < nparts; p += 64) s += part[((long)p * 64 + row) * ncols_tile + colt];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane != 0) return;
+    s *= scale;
+    if (is_w) {
+        const int b = col / KK, kl = col - b * KK;
+        if (transpose) out[((long)b * nA + ga) * KK + kl] = s;          // [b][a][k][l]
+        else out[((long)ga * nB + b) * KK + kl] = s;                    // [a][b][k][l]
+    } else if (is_rs) row_sums[ga] = s;
+    else { const int b = col / KK, kl = col - b * KK; if (kl == zero_tap) col_sums[b] = s; }
+}
+
+template <int NK> static hipError_t run_mcorr(MCorrArgs a, int B, float* out, int transpose, float* row_sums, float* col_sums, float scale, hipStream_t st)
+{
+    constexpr int KK = NK * NK;
+    const int bands = (a.Nx + 7) / 8;
+    const int nrows = a.nA + (a.ones_row ? 1 : 0), ncols = a.nB * KK + (a.ones_col ? 1 : 0);
+    const int zk = -a.ik0, zl = -a.il0;                                // the tap with zero shift (exists for the reference geometries)
+    const int zero_tap = (zk >= 0 && zk < NK && zl >= 0 && zl < NK) ? zk * NK + zl : -1;
+    if (col_sums && zero_tap < 0) return hipErrorInvalidValue;
+    const int ncb_all = (ncols + 31) / 32;
+    for (int row0 = 0; row0 < nrows; row0 += 64)
+        for (int cb0 = 0; cb0 < ncb_all; cb0 += 3) {
+            const int ncb = std::min(3, ncb_all - cb0);
+            a.row0 = row0; a.col0 = 32 * cb0;
+            if (ncb == 1) mcorr_kernel<NK, 1><<<dim3(bands, B), 256, 0, st>>>(a);
+            else if (ncb == 2) mcorr_kernel<NK, 2><<<dim3(bands, B), 256, 0, st>>>(a);
+            else mcorr_kernel<NK, 3><<<dim3(bands, B), 256, 0, st>>>(a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            msum_kernel<<<dim3((64 * 32 * ncb + 3) / 4), 256, 0, st>>>(a.part, bands * B, 32 * ncb, row0, 32 * cb0, a.nA, a.nB * KK, KK, a.nB, transpose, out,
+                                                                 row_sums, col_sums, zero_tap, scale);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+static size_t mcorr_part_floats(int Nx, int B) { return (size_t)B * ((Nx + 7) / 8) * 64 * 96; }
+
 // tile shapes: few A planes x few B planes such that TA*TB*NK*NK accumulators stay in registers
 template <int NK> struct WTile;
 template <> struct WTile<3> { static constexpr int TA = 2, TB = 3; };
@@ -471,7 +719,7 @@ size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl)
     if (Nk == 3) x = std::max(wcorr_part_floats<3>(dM, dD, Nx, B), wcorr_part_floats<3>(dD, dM, Nx, B));
     else if (Nk == 5) x = std::max(wcorr_part_floats<5>(dM, dD, Nx, B), wcorr_part_floats<5>(dD, dM, Nx, B));
     else x = std::max(wcorr_part_floats<7>(dM, dD, Nx, B), wcorr_part_floats<7>(dD, dM, Nx, B));
-    return x;
+    return std::max(x, mcorr_part_floats(Nx, B));
 }
 template <int NK> static hipError_t launch_wcorr(const WCorrArgs& a, int B, float* out, float* osum, float scale, hipStream_t st)
 {
@@ -699,6 +947,18 @@ hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
         hipError_t e = launch_dconv(g, a.Nk, a.B, st);
         if (e != hipSuccess) return e;
         const float scale = 1.0f / a.Norm / (float)a.B;
+        if (a.dM >= 8 && a.Ny % 4 == 0 && !flag(AEFFT_F_NOMFMA)) {
+            // both correlations as GEMMs on the matrix cores, rows = the dM planes (mcorr_kernel):
+            //   dC[m][d][k][l] = sum g[m][i][j] in[d][i-ik][j-il]                  rows g, columns in shifted by -tap, + ones column (dB)
+            //   dF[d][m][k][l] = sum s0[d][i][j] hin[m][i-ik][j-il]                 re-indexed by i' = i - ik: rows hin (masked below lo),
+            //                  = sum hin[m][i'][j'] s0[d][i'+ik][j'+il]             columns s0 shifted by +tap, + ones row (dP at the zero tap)
+            MCorrArgs mc{a.ws, a.dM, 0, a.in, nullptr, a.dD, a.lo, -1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 0, 1, 0, 0, a.part};
+            MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part};
+            if (a.Nk == 3) { e = run_mcorr<3>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
+            else if (a.Nk == 5) { e = run_mcorr<5>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<5>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
+            else { e = run_mcorr<7>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<7>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
+            return e;
+        }
         WCorrArgs wc{a.ws, nullptr, a.in, a.part, a.dM, a.dD, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, a.lo};       // dC, dB
         WCorrArgs wf{a.out, a.in, a.hin, a.part, a.dD, a.dM, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, a.lo};        // dF, dP
         if (a.Nk == 3) { e = launch_wcorr<3>(wc, a.B, a.gc, a.gb, scale, st); if (e == hipSuccess) e = launch_wcorr<3>(wf, a.B, a.gf, a.gp, scale, st); }
