@@ -24,7 +24,8 @@ Prints ONE JSON line (rank 0): metric/value per the driver contract, plus
   "roofline":     the dominant kernel's algorithmic bytes / its HIP-event-timed duration vs 8 TB/s
   "cpu_baseline": the reference's CPU path (oracle/_ref when built, else the C port) timed on this
                   host on a bounded sample (rank 0, N=1 only)
-  "variants":     short extra runs (rank 0, N=1 only): cfg3-P1 and a spatial-mode Conv+Conv+backprop step
+  "variants":     short extra runs (rank 0, N=1 only): the same workload in the per-frame form, cfg3-P1, and a spatial-mode
+                  Conv+Conv+backprop step
 """
 import argparse
 import importlib
@@ -167,6 +168,33 @@ def variant_p1(aefft, torch, np, ctx, steps=4):
     return {"workload": "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512)", "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
             "mse_finite": ok, "step_algo_GB": step_bytes / 1e9, "step_frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
             "dominant_kernel": {"name": name, "ms": dom["ms"], "GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] else 0.0}}
+
+
+def variant_per_frame(aefft, torch, np, ctx, steps=20):
+    """The headline workload in the PER-FRAME form (development switch NOOPFORM: every layer evaluated for every frame, round 1's
+    step) -- reported beside the operator form so that the gain of contracting the batch first is visible, not assumed."""
+    N, D, maps, Nk, B = 512, 3, [8, 16, 32, 64], 5, 32
+    ctx.set_flags("NOOPFORM")
+    try:
+        net = aefft.Net(ctx, D, N, N, maps, Nk, 2, batch=B)
+        init_weights(net, np)
+        dev = f"cuda:{ctx.device}"
+        frames = synth_frames(torch, B, D, N, dev, first_index=0)
+        recon = torch.empty_like(frames)
+        mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
+        for _ in range(5):
+            net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+        ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+        ctx.sync(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        mse_host = mse.cpu().numpy().tolist()
+        net.close()
+    finally:
+        ctx.set_flags()
+    return {"workload": "cfg3-P2, per-frame form (NOOPFORM)", "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps, "mse_per_pair": mse_host}
 
 
 def variant_spatial(aefft, torch, np, ctx, steps=5):
@@ -324,7 +352,8 @@ def main():
         net.close()
         del frames, recon
         torch.cuda.empty_cache()
-        variants = {"p1": variant_p1(aefft, torch, np, ctx), "spatial": variant_spatial(aefft, torch, np, ctx)}
+        variants = {"per_frame_form": variant_per_frame(aefft, torch, np, ctx), "p1": variant_p1(aefft, torch, np, ctx),
+                    "spatial": variant_spatial(aefft, torch, np, ctx)}
 
     if rank == 0:
         out = {
