@@ -5,8 +5,8 @@ path = sys.argv[1]
 f = glob.glob(path + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'aefft' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'r2c_rows_kernel<512>' in r['Kernel_Name']]
-s = idx[-1]
+idx = [i for i, r in enumerate(rows) if 'r2c_rows' in r['Kernel_Name']]
+s = idx[-1] if idx else 0
 t0 = int(rows[s]['Start_Timestamp']); tot = 0
 agg = {}
 for r in rows[s:]:
