@@ -144,7 +144,11 @@ extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, i
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
     if (!create_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
     else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
+        // the library's own stream carries the latency-bound chain of the step: highest priority, so that the bandwidth-bound
+        // side-stream work (reconstruction, input prefetch) takes the slots it leaves free instead of crowding it out
+        int pr_least = 0, pr_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, pr_greatest) != hipSuccess) { delete ctx; return AEFFT_EHIP; }
         ctx->own_stream = true;
     }
     if (upload_twiddles(ctx->stream) != hipSuccess) { if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream); delete ctx; return AEFFT_EHIP; }
@@ -172,7 +176,9 @@ static int ensure_aux(aefft_ctx* ctx)
     if (ctx->aux[0]) return AEFFT_OK;
     hipError_t e = hipSuccess;
     for (int i = 0; i < aefft_ctx::NAUX && e == hipSuccess; ++i) {
-        e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+        int pr_least = 0, pr_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        e = hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, pr_least);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
@@ -890,7 +896,8 @@ struct Pair {
     float2* G = nullptr;     // [dD][dD][P] collapsed pair operator F.C/(dM dD) (post-update MSE; innermost pair's forward)
     bool G_valid = false;    // G and beta (its DC bias) belong to the CURRENT weights (left by aefft_net_step_apply)
     float* beta = nullptr;   // [dD]
-    float* Q = nullptr;      // [dD][dD][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip)
+    float* Q = nullptr;      // [dD][dD][Qn][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip), Qn row-chunk partial sums
+    int Qn = 1;
     float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
     bool O_stale = false;    // the last (lazy) forward produced Oc only: expand before reading O
     float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
@@ -1051,7 +1058,8 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
                 else rc = net_alloc_t(n, &q.Oc, (size_t)n->Bc * q.dD * n->Pc);
                 if (rc == AEFFT_OK && q.Nk == q.Nl && (q.Nk == 3 || q.Nk == 5)) {
                     const size_t tt = (size_t)(2 * q.Nk - 1) * (2 * q.Nk - 1);
-                    rc = net_alloc_t(n, &q.Q, (size_t)q.dD * q.dD * tt);
+                    q.Qn = kgrad_group_chunks((long)q.dD * q.dD, q.Nx, q.Ny);       // room for the row chunks' partial sums
+                    rc = net_alloc_t(n, &q.Q, (size_t)q.dD * q.dD * tt * q.Qn);
                 }
             }
         }
@@ -1287,7 +1295,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         hipError_t e = launch_moment(n->Xf, n->Mhat, BF, n->D, n->pr[0].P, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "moment", e);
     }
-    bool chained = false;
+    bool chained = false, fork_recorded = false;
     if (chain_ok) {
         ChainArgs ca{};
         double bytes = 0;
@@ -1302,9 +1310,12 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
         ca.mom_Xf = n->Xf; ca.mom_M = n->Mhat; ca.mom_B = BF;            // the batch moments share the launch
         Bracket br(ctx, KID_CHAIN, bytes + mom_bytes);
-        hipError_t e = launch_chain(ca, ctx->cur);
+        // the reconstruction's side stream forks right behind this launch (below): its completion signal is the fork event
+        const bool fork_here = recon_d && lazy && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && !ctx->prof &&
+                               !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
+        hipError_t e = launch_chain(ca, ctx->cur, fork_here ? ctx->ev_fork : nullptr);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
-        chained = true;
+        chained = true; fork_recorded = fork_here;
     }
     for (int l = 0; l < L && !chained; ++l) {
         Pair& q = n->pr[l];
@@ -1416,7 +1427,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         if (async) {
             // training step: nothing downstream reads the reconstruction, so its (bandwidth-bound) inverse FFT runs on a side
             // stream underneath the latency-bound gradient contractions; aefft_net_step_grad joins it before returning
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            if (!fork_recorded) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
             ctx->cur = ctx->aux[0];
         }
@@ -1696,7 +1707,8 @@ static int grads_grouped(aefft_net* n)
             if (qpath) {
                 // weight gradients through Q = pruned inverse transform of S on the (2Nk-1)^2 offsets (weight_kernels.hip): no dc|df spectra
                 pg.q[l] = PrunedProb{q.S, q.Q, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
-                wg.q[l] = WgradProb{q.c, q.f, q.Q, q.es, q.b, g, g + nk, q.dM, q.dD, 1.0f / (Norm * (float)n->B), (float)q.Nx * (float)q.Ny};
+                pg.chunks[l] = q.Qn;
+                wg.q[l] = WgradProb{q.c, q.f, q.Q, q.es, q.b, g, g + nk, q.dM, q.dD, 1.0f / (Norm * (float)n->B), (float)q.Nx * (float)q.Ny, 1};
                 kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
                 wbytes += (2.0 * nk + (double)q.dD * q.dD * T * T) * 4.0 + 2.0 * nk * 4.0;
             } else {
@@ -1730,6 +1742,7 @@ static int grads_grouped(aefft_net* n)
                       : launch_kgrad_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
         }
         if (e == hipSuccess && qpath) {
+            for (int l = 0; l < n->L; ++l) wg.q[l].nq = pg.chunks[l];
             Bracket br(ctx, KID_WGRAD, wbytes);
             e = launch_wgrad_taps_group(wg, n->pr[0].Nk, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "wgrad(group)", e);
@@ -2006,8 +2019,10 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
         ctx->recon_join = true;
     }
     if (n->recon_pending) {
+        // joined where the deferred form is: by aefft_net_step_apply (after its last launch), aefft_sync or the next call on this
+        // net -- nothing the update half launches touches what the reconstruction reads or writes
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+        ctx->recon_join = true;
         n->recon_pending = false;
     }
     n->have_grad = true;

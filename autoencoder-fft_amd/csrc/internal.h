@@ -109,7 +109,13 @@ hipError_t launch_kgrad(const float2* D, float* g, float* part /*workspace: kgra
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
 // The same transforms for up to 8 problems with equal (Nk, Nl) in ONE launch (kgrad: no row chunks, so no ksum pass).
 struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale; };
-struct PrunedGroup { PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8]; };
+struct PrunedGroup {
+    PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8];
+    // grouped inverse transform only: rows per slice; chunks[p] in: row chunks dst has room for ([planes][chunks][taps], 0/1 = none),
+    // out: the chunks the launch used (the consumer adds them in order)
+    int rb[8], chunks[8];
+};
+int kgrad_group_chunks(long planes, int Nx, int Ny);
 struct PackArgs;
 hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed = nullptr /* the bin-major copy rides along as extra workgroups */);
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
@@ -118,7 +124,7 @@ hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
 hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);
 
 // ---- weight_kernels.hip ----------------------------------------------------------------
-struct WgradProb { const float *c, *f, *Q, *es, *b; float *gc, *gf; int dM, dD; float inv_den, norm; };   // Q [dD][dD][T*T], es [2*dD]
+struct WgradProb { const float *c, *f, *Q, *es, *b; float *gc, *gf; int dM, dD; float inv_den, norm; int nq; };   // Q [dD][dD][nq][T*T] (nq row-chunk partial sums, added here), es [2*dD]
 struct WgradGroup { WgradProb q[8]; int n; int start[9]; };
 hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st);
 struct GspProb { const float *c, *f; float* gsp; int dM, dD; float scale; };                                // gsp [dD][dD][T*T]
@@ -171,7 +177,7 @@ struct ChainArgs {
     int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
     const float2* mom_Xf; float2* mom_M; int mom_B;   // nullable: the batch moments M^ ride along as trailing workgroups (moment_body)
 };
-hipError_t launch_chain(ChainArgs& g, hipStream_t st);
+hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done = nullptr /* recorded by the dispatch itself */);
 // Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps
 struct PackSeg { const float* k; int n, lev, off; };              // taps [n][Nk*Nk] of one tensor, its pair, its element offset in a record
 struct PackArgs { PackSeg seg[16]; int nseg, L, E, Nk; int Nx[8], Ny[8]; int NxC, NyC; long Pc; float2* Wp; const float2* tw;

@@ -13,6 +13,7 @@
 // Same sums, batch contracted first (float32 rounding only); parity: tests/test_gpu_fft_path.py::test_step_*.
 #include "../../include/aefft.h"
 #include "internal.h"
+#include <hip/hip_ext.h>
 #include "device_util.h"
 #include "opform_device.h"
 #include <algorithm>
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
     }
 }
 
-hipError_t launch_chain(ChainArgs& g, hipStream_t st)
+hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
 {
     if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
     for (int l = 0; l < g.L; ++l) {
@@ -626,7 +627,9 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st)
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
     g.vt_elems = rmax * OPC * CH_BT;
     const size_t lds = sizeof(float2) * 2 * g.vt_elems;
-    chain_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
+    // `done`: recorded by this dispatch's own completion signal (no marker packet behind it on the stream: a side stream forks here)
+    if (done) hipExtLaunchKernelGGL(chain_kernel, dim3((unsigned)total), dim3(256), lds, st, nullptr, done, 0, g);
+    else chain_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 

@@ -195,61 +195,76 @@ __global__ __launch_bounds__(320) void kgrad_kernel(const float2* __restrict__ D
     kgrad_body<NK, NL>(D, part, tw, planes, Nx, Ny, RB, ppb, scale, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
-// Grouped form: all pairs' pruned inverse transforms in ONE launch and without partial sums in HBM.  A workgroup of NT
-// threads owns ppb planes; thread <-> (row slice s, plane, column j), so a 256-row plane is walked by S slices in
-// parallel (3 load round trips instead of 16) and the slices are combined in LDS in a fixed order (deterministic).
+// Grouped form: all pairs' pruned inverse transforms in ONE launch.  A workgroup of NT threads owns ppb planes x one chunk of
+// CR = S*RB rows; thread <-> (row slice s, plane, column j) walks RB rows (one batch of 16 loads when the problem is chunked),
+// the slices are combined in LDS in a fixed order.  Row chunks leave their partial sums side by side ([plane][chunk][tap]) and
+// the NEXT kernel adds them in chunk order while staging (an in-launch combine by the last workgroup to arrive was measured at
+// 3.6x the whole kernel: its agent-scope release writes back the XCD's L2, which is full of freshly written S).
+// The global loads of the first batch are issued BEFORE the phase tables are built: the table gathers ride in their shadow.
 template <int NK, int NL, int NT>
 __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, float* __restrict__ g, const float2* __restrict__ tw,
-                                                  long planes, int Nx, int Ny, int ppb, int S, float scale, int bx, float2* lds)
+                                                  long planes, int Nx, int Ny, int ppb, int S, int RB, int nchunks, float scale,
+                                                  int bx, int chunk, float2* lds)
 {
     constexpr int TS = NT + 1;                                      // row stride of the t arrays (+1: the NK rows land in different banks)
+    constexpr int TT = NK * NL;
     const int Nyr = Ny / 2 + 1;
-    float2* rowph = lds;                                            // [Nx][NK]   e^{+2 pi i i kap_k / Nx}
-    float2* colph = rowph + Nx * NK;                                // [Nyr][NL]  e^{+2 pi i j lam_l / Ny}
+    const int CR = S * RB;                                          // rows of this chunk (the last one may hold fewer)
+    const int r0 = chunk * CR, crow = min(CR, Nx - r0);
+    float2* rowph = lds;                                            // [CR][NK]   e^{+2 pi i i kap_k / Nx}
+    float2* colph = rowph + CR * NK;                                // [Nyr][NL]  e^{+2 pi i j lam_l / Ny}
     float* tre = reinterpret_cast<float*>(colph + Nyr * NL);        // [NK][TS]   per-thread row sums t_k (real part)
     float* tim = tre + NK * TS;                                     // [NK][TS]
-    for (int t = threadIdx.x; t < Nx * NK; t += NT) rowph[t] = phase(tw, t / NK, t % NK - NK / 2, Nx, -1.f);
-    for (int t = threadIdx.x; t < Nyr * NL; t += NT) colph[t] = phase(tw, t / NL, t % NL - NL / 2, Ny, -1.f);
-    __syncthreads();
     const int per = ppb * Nyr;
     const int s = threadIdx.x / per, rem = threadIdx.x - s * per;
     const int pl = rem / Nyr, j = rem - pl * Nyr;
     const long plane = (long)bx * ppb + pl;
     const bool active = s < S && plane < planes;
-    const int RB = (Nx + S - 1) / S;
-    const int i0 = s * RB, nrows = active ? min(RB, Nx - i0) : 0;
+    const int i0 = s * RB, nrows = active ? max(0, min(RB, crow - i0)) : 0;
+    const float2* src = D + (plane * Nx + r0 + i0) * (long)Nyr + j;
+    float2 d[16];
+    if (nrows > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) d[u] = src[(long)min(u, nrows - 1) * Nyr];
+    }
+    // phase tables: batches of independent gathers (a rolled load -> store loop is one L2 round trip per entry)
+    for (int t0 = 0; t0 < CR * NK; t0 += NT * 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, CR * NK - 1); v[u] = phase(tw, (r0 + t / NK) & (Nx - 1), t % NK - NK / 2, Nx, -1.f); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < CR * NK) rowph[t] = v[u]; }
+    }
+    for (int t0 = 0; t0 < Nyr * NL; t0 += NT * 5) {
+        float2 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, Nyr * NL - 1); v[u] = phase(tw, t / NL, t % NL - NL / 2, Ny, -1.f); }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < Nyr * NL) colph[t] = v[u]; }
+    }
+    __syncthreads();
     float2 t[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) t[k] = make_float2(0.f, 0.f);
     if (nrows > 0) {
-        const float2* src = D + (plane * Nx + i0) * (long)Nyr + j;
         const float2* rp0 = rowph + i0 * NK;
-        int i = 0;
-        for (; i + 16 <= nrows; i += 16) {
-            float2 d[16];
+        for (int i = 0; i < nrows; i += 16) {
+            if (i > 0) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) d[u] = src[(long)(i + u) * Nyr];
+                for (int u = 0; u < 16; ++u) d[u] = src[(long)min(i + u, nrows - 1) * Nyr];
+            }
+            if (i + 16 > nrows) {                         // tail batch: rows past the slice were read clamped, they count zero
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const float2 rp = rp0[(i + u) * NK + k];
-                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
-                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
-                }
-        }
-        if (i < nrows) {                                  // tail: clamped loads, masked accumulation (one more round trip, not nrows-i)
-            float2 d[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) d[u] = src[(long)min(i + u, nrows - 1) * Nyr];
+                for (int u = 0; u < 16; ++u) if (i + u >= nrows) d[u] = make_float2(0.f, 0.f);
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                if (i + u >= nrows) break;
+                const float2* rp = rp0 + min(i + u, nrows - 1) * NK;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    const float2 rp = rp0[(i + u) * NK + k];
-                    t[k].x += d[u].x * rp.x - d[u].y * rp.y;
-                    t[k].y += d[u].x * rp.y + d[u].y * rp.x;
+                    const float2 r = rp[k];
+                    t[k].x += d[u].x * r.x - d[u].y * r.y;
+                    t[k].y += d[u].x * r.y + d[u].y * r.x;
                 }
             }
         }
@@ -270,7 +285,7 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
     __syncthreads();
     // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ): the columns of a plane are split over JS threads per output
     // (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums combined in slice order
-    const int nout = ppb * NK * NL;
+    const int nout = ppb * TT;
     int JS = NT / nout;
     if (JS < 1) JS = 1;
     if (JS > 16) JS = 16;
@@ -278,7 +293,7 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
     float* part = tim + NK * TS;                          // [nout][JS], after the t arrays
     for (int it = threadIdx.x; it < nout * JS; it += NT) {
         const int o = it / JS, js = it - o * JS;
-        const int p2 = o / (NK * NL), kl = o - p2 * (NK * NL);
+        const int p2 = o / TT, kl = o - p2 * TT;
         const int k = kl / NL, l = kl - k * NL;
         float a = 0.f;
         const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
@@ -291,12 +306,12 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
     }
     __syncthreads();
     for (int o = threadIdx.x; o < nout; o += NT) {
-        const int p2 = o / (NK * NL), kl = o - p2 * (NK * NL);
+        const int p2 = o / TT, kl = o - p2 * TT;
         const long pln = (long)bx * ppb + p2;
         if (pln >= planes) continue;
         float a = 0.f;
         for (int js = 0; js < JS; ++js) a += part[o * JS + js];
-        g[pln * (NK * NL) + kl] = a * scale;
+        g[(pln * nchunks + chunk) * TT + kl] = a * scale;       // [plane][chunk][tap]: the consumer adds the chunks in order
     }
 }
 
@@ -318,8 +333,9 @@ __global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, co
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const PrunedProb& q = g.q[p];
+    const int lin = blockIdx.x - g.start[p];
     kgrad_sliced_body<NK, NL, NT>(static_cast<const float2*>(q.src), static_cast<float*>(q.dst), tw, q.planes, q.Nx, q.Ny, g.ppb[p], g.rows[p],
-                                  q.scale, blockIdx.x - g.start[p], lds);
+                                  g.rb[p], g.chunks[p], q.scale, lin % g.pblocks[p], lin / g.pblocks[p], lds);
 }
 
 // g[e] = sum_chunk part[plane][chunk][tap]
@@ -426,25 +442,46 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     return hipGetLastError();
 }
 
+// geometry of one problem of the grouped inverse transform
+struct KgGeom { int ppb, S, RB, chunks, pblocks; };
+static constexpr int KG_NT = 512, KG_MAXCHUNKS = 8;
+static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
+{
+    KgGeom o{};
+    const int Nyr = Ny / 2 + 1;
+    o.ppb = std::max(1, std::min(256, KG_NT) / Nyr);      // ~256 columns per workgroup, the remaining threads become row slices
+    if (o.ppb > planes) o.ppb = (int)planes;
+    o.S = std::max(1, KG_NT / (o.ppb * Nyr));
+    while (o.S > 1 && Nx / o.S < 8) --o.S;
+    o.RB = (Nx + o.S - 1) / o.S;
+    o.chunks = 1;
+    const int cap = std::min(KG_MAXCHUNKS, max_chunks);
+    if (cap > 1 && o.RB > 16) {
+        // one 16-row load batch per slice and chunk while the destination has room for the chunks' partial sums
+        int cr = 16 * o.S;
+        o.chunks = (Nx + cr - 1) / cr;
+        if (o.chunks > cap) { o.chunks = cap; cr = (Nx + cap - 1) / cap; }
+        o.RB = (cr + o.S - 1) / o.S;
+        o.chunks = (Nx + o.S * o.RB - 1) / (o.S * o.RB);
+    }
+    o.pblocks = (int)((planes + o.ppb - 1) / o.ppb);
+    return o;
+}
+// row chunks the grouped inverse transform would like for this problem: size the destination [planes][chunks][taps]
+int kgrad_group_chunks(long planes, int Nx, int Ny) { return kgrad_group_geom(planes, Nx, Ny, KG_MAXCHUNKS).chunks; }
+
 template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st, BiasGradGroup* bgp = nullptr)
 {
-    // (512-thread workgroups were tried: 32.5 us against 30.1 us -- the few big planes of pair 0 are the long pole, not residency)
-    constexpr int NT = 1024;
+    constexpr int NT = KG_NT;
     int total = 0; size_t lds = 0;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         const int Nyr = q.Ny / 2 + 1;
         if (Nyr > NT) return hipErrorInvalidValue;
-        // planes per workgroup as in the single-problem kernel (~256 columns), the remaining threads become row slices (>= 8 rows each)
-        g.ppb[p] = std::max(1, std::min(256, NT) / Nyr);
-        // few planes (the dD x dD planes of S): fewer planes per workgroup so that the launch still has a few hundred of them
-        while (g.ppb[p] > 1 && (q.planes + g.ppb[p] - 1) / g.ppb[p] < 256) g.ppb[p] = (g.ppb[p] + 1) / 2;
-        int S = std::max(1, NT / (g.ppb[p] * Nyr));
-        while (S > 1 && q.Nx / S < 8) --S;
-        g.rows[p] = S;
-        g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
-        g.start[p] = total; total += g.pblocks[p];
-        lds = std::max(lds, sizeof(float2) * ((size_t)q.Nx * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + (size_t)std::max(NT, g.ppb[p] * NK * NL)));
+        const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::max(1, g.chunks[p]));     // in: room at dst; out: chunks used
+        g.ppb[p] = k.ppb; g.rows[p] = k.S; g.rb[p] = k.RB; g.chunks[p] = k.chunks; g.pblocks[p] = k.pblocks;
+        g.start[p] = total; total += k.pblocks * k.chunks;
+        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + (size_t)std::max(NT, k.ppb * NK * NL)));
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;

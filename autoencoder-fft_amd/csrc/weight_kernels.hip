@@ -42,17 +42,43 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
     float* red = ws + dD * TM * KK;
     // staging in batches of 8 independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
     // one memory round trip per element otherwise)
-    for (int t0 = 0; t0 < dD * TT; t0 += 256 * 12) {
-        float v[12];
+    const int nq = q.nq;
+    if (nq <= 1) {
+        for (int t0 = 0; t0 < dD * TT; t0 += 256 * 12) {
+            float v[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            if (t0 + u * 256 >= dD * TT) break;                       // uniform
-            const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
-            const int d1 = t / TT, r = t - d1 * TT;
-            v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
+            for (int u = 0; u < 12; ++u) {
+                if (t0 + u * 256 >= dD * TT) break;                       // uniform
+                const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
+                const int d1 = t / TT, r = t - d1 * TT;
+                v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
         }
+    } else {
+        // the producer left nq row-chunk partial sums per plane ([plane][chunk][tap]): added here in chunk order, 4 elements x 4
+        // chunks of independent loads per batch
+        for (int t0 = 0; t0 < dD * TT; t0 += 256 * 4) {
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c0 = 0; c0 < nq; c0 += 4) {
+                float v[4][4];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
+                for (int u = 0; u < 4; ++u) {
+                    const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
+                    const int d1 = t / TT, r = t - d1 * TT;
+                    const long pl = isf ? (long)a * dD + d1 : (long)d1 * dD + a;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[u][c] = q.Q[(pl * nq + min(c0 + c, nq - 1)) * TT + r];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c0 + c < nq) acc4[u] += v[u][c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = acc4[u]; }
+        }
     }
     // (24 loads per thread in flight: the weight slab of the innermost pair is 37 loads per thread, i.e. two round trips, not five)
     for (int t0 = 0; t0 < dD * TM * KK; t0 += 256 * 24) {
