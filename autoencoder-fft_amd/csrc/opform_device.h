@@ -35,58 +35,76 @@ __device__ __forceinline__ float2 phase_tw(const float2* tw, int pos, int off, i
     return tw[((pos * off) & (N - 1)) * (TW_N / N)];
 }
 
+// the two halves of map_up: row i / column j of the small grid -> row / column of the big grid
+__device__ __forceinline__ int map_up_row(int i, int Nx, int NxB) { return i < Nx / 2 ? i : (i == Nx / 2 ? NxB / 2 : i + NxB - Nx); }
+__device__ __forceinline__ int map_up_col(int j, int Ny, int NyB) { return j < Ny / 2 ? j : NyB / 2; }
+
+// complex helpers on the native 2-vector (v_pk_* instructions)
+__device__ __forceinline__ float2 pk_scale(float s, float2 a) { return make_float2(s, s) * a; }
+__device__ __forceinline__ float2 pk_cmul(float2 a, float2 b)
+{
+    const float2 ax = make_float2(a.x, a.x), ay = make_float2(a.y, a.y), bs = make_float2(-b.y, b.x);
+    return ax * b + ay * bs;
+}
+
 // Wp[t][e]: for support bin t the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 (chain order) at the bins of their grids that t
-// maps to.  Workgroup = 256 consecutive elements x TB support bins; thread = one element: its Nk*Nl taps stay in registers,
-// per bin the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} and then sum_k v_k e^{-2 pi i i kap_k / Nx}
-// (the association of kspec_body).  Stores are coalesced along e.
+// maps to.  Workgroup = 256 consecutive elements x ONE column j of the support x PACK_RG of its rows; thread = one element: its
+// Nk*Nl taps stay in registers, the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} is formed once (the association of
+// kspec_body) and every row then costs Nk complex multiplies: sum_k v_k e^{-2 pi i i kap_k / Nx}.  Stores are coalesced along e.
+constexpr int PACK_RG = 16;                     // (8: 25.2 us, 16: 22.9, 32: 29.5 for the merged launch at cfg3, with the 1024-workgroup target below)
+static inline int pack_yblocks(const PackArgs& g) { return (g.NyC / 2 + 1) * ((g.NxC + PACK_RG - 1) / PACK_RG); }
 template <int NK>
 __device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int by)
 {
-    constexpr int TB = 8, KK = NK * NK;
-    __shared__ float2 ph[TB][2][NK];                               // [bin][row/col][tap] phases on this tensor's grid
+    constexpr int RG = PACK_RG, KK = NK * NK;
+    __shared__ float2 ph[RG + 1][NK];                              // row phases of the RG rows, then the column's, on this tensor's grid
     __shared__ float taps[256 * KK];                               // the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
     const PackSeg sd = g.seg[g.blk_seg[bx]];               // (uniform: a workgroup's elements belong to ONE tensor)
     const int l0 = g.blk_start[bx];                        // first element of the block inside the tensor
     const int nel = min(256, sd.n - l0);
-    const int t0 = by * TB;
+    const int nyrc = g.NyC / 2 + 1;
+    const int j = by % nyrc, i0 = (by / nyrc) * RG;
     const bool wk = threadIdx.x < 256;                               // (hosted by kernels with larger workgroups: the extra threads only meet the barrier)
-    for (int i = threadIdx.x; i < TB * 2 * NK; i += blockDim.x) {
-        const int k = i % NK, rc = (i / NK) & 1, b = i / (2 * NK);
-        const int t = min(t0 + b, (int)g.Pc - 1);
-        const long s = map_up(t, g.NxC, g.NyC, g.Nx[sd.lev], g.Ny[sd.lev]);
-        const int nyr = g.Ny[sd.lev] / 2 + 1;
-        const int bi = (int)((unsigned)s / (unsigned)nyr), bj = (int)((unsigned)s - (unsigned)bi * nyr);
-        ph[b][rc][k] = rc == 0 ? phase_tw(g.tw, bi, k - NK / 2, g.Nx[sd.lev]) : phase_tw(g.tw, bj, k - NK / 2, g.Ny[sd.lev]);
-    }
     if (wk) {
         const float* src = sd.k + (long)l0 * KK;                   // nel * KK consecutive floats
         const int nf = nel * KK;
         float v[KK];                                               // every load of the copy in flight at once: one round trip
 #pragma unroll
         for (int w = 0; w < KK; ++w) v[w] = src[min(w * 256 + (int)threadIdx.x, nf - 1)];
+        float2 pv = make_float2(0.f, 0.f);                         // (the phase gathers ride in the same round trip)
+        if (threadIdx.x < (RG + 1) * NK) {
+            const int k = threadIdx.x % NK, r = threadIdx.x / NK;
+            const int NxB = g.Nx[sd.lev], NyB = g.Ny[sd.lev];
+            pv = r < RG ? phase_tw(g.tw, map_up_row(min(i0 + r, g.NxC - 1), g.NxC, NxB), k - NK / 2, NxB)
+                        : phase_tw(g.tw, map_up_col(j, g.NyC, NyB), k - NK / 2, NyB);
+        }
 #pragma unroll
         for (int w = 0; w < KK; ++w) { const int f = w * 256 + threadIdx.x; if (f < nf) taps[f] = v[w]; }
+        if (threadIdx.x < (RG + 1) * NK) ph[threadIdx.x / NK][threadIdx.x % NK] = pv;
     }
     __syncthreads();
     if (!wk || (int)threadIdx.x >= nel) return;
     const int e = sd.off + l0 + threadIdx.x;
-    float c[NK * NK];
+    float2 v[NK];
+    {
+        float2 cp[NK];
 #pragma unroll
-    for (int i = 0; i < NK * NK; ++i) c[i] = taps[threadIdx.x * KK + i];
-    for (int b = 0; b < TB && t0 + b < g.Pc; ++b) {
-        float2 cp[NK], rp[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { rp[k] = ph[b][0][k]; cp[k] = ph[b][1][k]; }
-        float2 acc = make_float2(0.f, 0.f);
+        for (int l = 0; l < NK; ++l) cp[l] = ph[RG][l];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            float2 v = make_float2(0.f, 0.f);
+            v[k] = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int l = 0; l < NK; ++l) { v.x += c[k * NK + l] * cp[l].x; v.y += c[k * NK + l] * cp[l].y; }
-            acc.x += v.x * rp[k].x - v.y * rp[k].y;
-            acc.y += v.x * rp[k].y + v.y * rp[k].x;
+            for (int l = 0; l < NK; ++l) v[k] = v[k] + pk_scale(taps[threadIdx.x * KK + k * NK + l], cp[l]);
         }
-        g.Wp[(long)(t0 + b) * g.E + e] = acc;
+    }
+    float2* dst = g.Wp + ((long)i0 * nyrc + j) * g.E + e;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        if (i0 + r >= g.NxC) break;
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) acc = acc + pk_cmul(v[k], ph[r][k]);
+        dst[(long)r * nyrc * g.E] = acc;
     }
 }
 

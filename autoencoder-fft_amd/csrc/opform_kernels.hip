@@ -510,7 +510,7 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 {
     if (g.nseg < 1 || g.nseg > 16 || g.L < 1 || g.L > 8 || g.E < 1 || (g.Nk != 3 && g.Nk != 5)) return hipErrorInvalidValue;
     pack_blocks(g);
-    const dim3 grid((unsigned)g.nblk, (unsigned)((g.Pc + 7) / 8));
+    const dim3 grid((unsigned)g.nblk, (unsigned)pack_yblocks(g));
     if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, 0, st>>>(g);
     else kspec_packed_kernel<5><<<grid, 256, 0, st>>>(g);
     return hipGetLastError();

@@ -59,18 +59,14 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
         for (int k = 0; k < NK; ++k) {
             v[k] = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int l = 0; l < NL; ++l) { const float w = c[k * NL + l]; v[k].x += w * cp[l].x; v[k].y += w * cp[l].y; }
+            for (int l = 0; l < NL; ++l) v[k] = v[k] + pk_scale(c[k * NL + l], cp[l]);
         }
     }
     float2* dst = K + (plane * Nx + i0) * (long)Nyr + j;
     for (int i = 0; i < nrows; ++i) {
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const float2 rp = rowph[i * NK + k];
-            acc.x += v[k].x * rp.x - v[k].y * rp.y;
-            acc.y += v[k].x * rp.y + v[k].y * rp.x;
-        }
+        for (int k = 0; k < NK; ++k) acc = acc + pk_cmul(v[k], rowph[i * NK + k]);
         dst[(long)i * Nyr] = acc;
     }
 }
@@ -426,8 +422,8 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
-        int chunks = 1;                                   // rows split until the LAUNCH has ~2048 workgroups (>= 8 rows each)
-        while (pb_all * chunks < 2048 && q.Nx / (chunks * 2) >= 8) chunks *= 2;
+        int chunks = 1;                                   // rows split until the LAUNCH has ~1024 workgroups (>= 8 rows each)
+        while (pb_all * chunks < 1024 && q.Nx / (chunks * 2) >= 8) chunks *= 2;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
         g.start[p] = total; total += g.pblocks[p] * chunks;
         lds = std::max(lds, kspec_lds(g.rows[p], NK));
@@ -437,7 +433,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
     if (threads > 320) return hipErrorInvalidValue;
     int extra = 0;
-    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * (int)((pk->Pc + 7) / 8); }
+    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); }
     kspec_group_kernel<NK, NL><<<dim3(total + extra), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none);
     return hipGetLastError();
 }
