@@ -134,7 +134,7 @@ template <int N> __device__ __forceinline__ void pass_sync()
 }
 
 template <int N, int R, int S, int DIR>
-__device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
+__device__ __forceinline__ void fft_pass(float2* s, int t, float2 w1)
 {
     constexpr int T = N / 8;
     constexpr int E = 8 / R;
@@ -152,15 +152,15 @@ __device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
         const int ib = t + T * v;
         const int p = ib / S, q = ib % S;
         Dft<R, DIR>::run(&a[v * R]);
-        if (n > R) {
-            // W_n^(p*u) = W_N^(p*u*S) from the workgroup's LDS copy of the N-point table (p*u < n)
-            const int base = p * S;
-#pragma unroll
-            for (int u = 1; u < R; ++u) {
-                float2 w = tws[u * base];
-                if (DIR > 0) w.y = -w.y;
-                a[v * R + u] = cmul(a[v * R + u], w);
-            }
+        if constexpr (n > R) {
+            // W_n^(p*u), u = 1..7, from the pass's base twiddle w1 = W_n^p (FftTw: an exact table entry) by at most three
+            // multiplications each: w2 = w1^2, w3 = w2 w1, w4 = w2^2, w5 = w4 w1, w6 = w3^2, w7 = w4 w3  (a twiddled pass
+            // always has R = 8 and one butterfly per thread; relative error of a power <= ~4e-7, inside the FFT's own round-off)
+            static_assert(R == 8 && E == 1, "twiddled passes are radix 8");
+            const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+            const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+            a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], w5); a[6] = cmul(a[6], w6); a[7] = cmul(a[7], w7);
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) s[pad_idx(q + S * (R * p + u))] = a[v * R + u];
@@ -169,29 +169,42 @@ __device__ __forceinline__ void fft_pass(float2* s, int t, const float2* tws)
     else pass_sync<N>();
 }
 
-template <int N, int S, int DIR> struct Passes {
-    static __device__ __forceinline__ void run(float2* s, int t, const float2* tws)
+// Base twiddles of the (at most three) twiddled passes of this thread's butterflies: pass i has stride S = 8^i and needs
+// W_{N/S}^p = W_N^(p*S), p = t / S.  Loaded from the global table at the top of a kernel, in the shadow of its data loads
+// (no per-workgroup LDS copy of the table: 4 KB of LDS and 2 table loads + 14 LDS reads per thread less at N = 512).
+template <int N, int DIR> struct FftTw {
+    float2 w[3];
+    __device__ __forceinline__ void load(int t)
+    {
+        constexpr int S[3] = {1, 8, 64};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            w[i] = make_float2(1.f, 0.f);
+            if (N / S[i] > 8) {
+                float2 v = g_tw[((t / S[i]) * S[i]) * (TW_N / N)];
+                if (DIR > 0) v.y = -v.y;
+                w[i] = v;
+            }
+        }
+    }
+};
+
+template <int N, int S, int I, int DIR> struct Passes {
+    static __device__ __forceinline__ void run(float2* s, int t, const FftTw<N, DIR>& tw)
     {
         constexpr int n = N / S;
         constexpr int R = n >= 8 ? 8 : n;
-        fft_pass<N, R, S, DIR>(s, t, tws);
-        Passes<N, S * R, DIR>::run(s, t, tws);
+        fft_pass<N, R, S, DIR>(s, t, tw.w[I < 3 ? I : 2]);
+        Passes<N, S * R, I + 1, DIR>::run(s, t, tw);
     }
 };
-template <int N, int DIR> struct Passes<N, N, DIR> {
-    static __device__ __forceinline__ void run(float2*, int, const float2*) {}
+template <int N, int I, int DIR> struct Passes<N, N, I, DIR> {
+    static __device__ __forceinline__ void run(float2*, int, const FftTw<N, DIR>&) {}
 };
 
 // Caller must have issued __syncthreads() after filling `s`; on return the result is in `s`
 // (natural order) and visible to the whole workgroup.
-template <int N, int DIR> __device__ __forceinline__ void fft_lds(float2* s, int t, const float2* tws) { Passes<N, 1, DIR>::run(s, t, tws); }
-
-// Copy the N-point twiddle table W_N^k, k < N, into LDS (once per workgroup): the passes then read twiddles
-// from LDS instead of issuing 7 global loads per thread and pass through the texture path.
-template <int N, int NT> __device__ __forceinline__ void load_twiddles(float2* tws)
-{
-    for (int i = threadIdx.x; i < N; i += NT) tws[i] = g_tw[i * (TW_N / N)];
-}
+template <int N, int DIR> __device__ __forceinline__ void fft_lds(float2* s, int t, const FftTw<N, DIR>& tw) { Passes<N, 1, 0, DIR>::run(s, t, tw); }
 
 // ------------------------------------------------------------------------------------------
 // row pass, forward: real rows -> packed half spectra
@@ -223,11 +236,11 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     using Cfg = RowCfg<N>;
     constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
     extern __shared__ float2 s[];
-    float2* tws = s + G * PL;
-    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const int g = tid / T, t = tid % T;
     const long pair0 = (long)blockIdx.x * G;
+    FftTw<N, -1> tws;
+    tws.load(t);
 
     constexpr int NV = G * 2 * N / 4;
     const float4* src = reinterpret_cast<const float4*>(in + pair0 * 2 * N);
@@ -276,11 +289,11 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     using Cfg = RowCfg<N>;
     constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
     extern __shared__ float2 s[];
-    float2* tws = s + G * PL;
-    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
     const int g = tid / T, t = tid % T;
     const long pair0 = (long)blockIdx.x * G;
+    FftTw<N, +1> tws;
+    tws.load(t);
 
     // Z[k] = A[k] + i*B[k], Z[N-k] = conj(A[k]) + i*conj(B[k]); k handled in pairs (k, k+1), k even < N/2
     constexpr int NIT = G * (N / 4) / NT;                       // = 2 when NT = G*N/8
@@ -358,9 +371,9 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
 {
     constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
     extern __shared__ float2 s[];
-    float2* tws = s + CW * PL;
-    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
+    FftTw<N, -1> tws;
+    tws.load(tid % T);
     const long plane = blockIdx.x;
     const int c0 = blockIdx.y * CW;
 
@@ -427,9 +440,9 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
 {
     constexpr int T = N / 8, NT = CW * T, PL = pad_len(N);
     extern __shared__ float2 s[];
-    float2* tws = s + CW * PL;
-    load_twiddles<N, NT>(tws);
     const int tid = threadIdx.x;
+    FftTw<N, +1> tws;
+    tws.load(tid % T);
     const long plane = blockIdx.x;
     const int c0 = blockIdx.y * CW;
     const int Nyri = Wc + 1;
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
     // Only Nxi of the N rows carry data (the rest is the zero padding of the spectral up-sampling): zero the tile, then ALL loads
     // of the Nxi x CW source elements in one batch (a rolled load -> store loop is one memory round trip per iteration), then the
     // scatter to the padded rows.  The two self-conjugate columns of column 0 are parked in LDS and symmetrised afterwards.
-    float2* dcs = tws + N;                                          // [Nxi] column 0 (DC) and [Nxi] Nyquist column, when c0 == 0
+    float2* dcs = s + CW * PL;                                        // [Nxi] column 0 (DC) and [Nxi] Nyquist column, when c0 == 0
     float2* nys = dcs + Nxi;
     if (Nxi < N) {
         for (int it = tid; it < CW * PL; it += NT) s[it] = make_float2(0.f, 0.f);
@@ -507,7 +520,7 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
 template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, long npairs, int Wc, hipStream_t st)
 {
     using Cfg = RowCfg<N>;
-    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL + N);
+    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL);
     hipError_t e = allow_lds(r2c_rows_kernel<N>, lds);
     if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
@@ -517,7 +530,7 @@ template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, lo
 template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, long npairs, int Wc, float scale, hipStream_t st)
 {
     using Cfg = RowCfg<N>;
-    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL + N);
+    const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL);
     hipError_t e = allow_lds(c2r_rows_kernel<N>, lds);
     if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
@@ -526,7 +539,7 @@ template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, l
 }
 template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st)
 {
-    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N);
+    const size_t lds = sizeof(float2) * (CW * pad_len(N));
     hipError_t e = allow_lds(fwd_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
     fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
@@ -535,7 +548,7 @@ template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float
 static OpIn g_opin_none{};
 template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2* mid, long planes, int Wc, int Nxi, hipStream_t st, const OpIn& op = g_opin_none)
 {
-    const size_t lds = sizeof(float2) * (CW * pad_len(N) + N + 2 * Nxi);
+    const size_t lds = sizeof(float2) * (CW * pad_len(N) + 2 * Nxi);
     hipError_t e = allow_lds(inv_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
     inv_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(in, mid, Wc, Nxi, op);
