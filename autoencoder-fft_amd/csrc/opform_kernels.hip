@@ -390,6 +390,117 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
     }
 }
 
+// Pairs with few maps (dM == DM = 8, dD <= 4: the outermost pair, which has the most bins): the generic body spends its time in
+// three dependent memory round trips separated by barriers for a few loads each.  Here every global load of the workgroup -- the
+// A tile, this thread's row of C', its row of F', the 4x4 moments -- is issued up front (one round trip), then the same two
+// small products run out of LDS.  Workgroup = 32 bins x 8 row threads.
+// element `e` of a uniform base with a 32-bit BYTE offset: the load takes the scalar-base + 32-bit lane offset form (callers
+// guarantee e * 8 < 2^32)
+__device__ __forceinline__ float2 ld8(const float2* base, unsigned e) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + e * 8u); }
+
+template <int DM>
+__device__ __forceinline__ void opmse_small_body(const OpMseGroup& g, int p, float2* sh)
+{
+    constexpr int BT = 32, RT = 256 / BT, DDMAX = 4;
+    static_assert(DM == RT, "one row of C' per row thread");
+    const OpMsePair q = g.q[p];
+    const int dD = q.dD;
+    float2* As = sh;                                                 // [OPC][dD][BT]
+    float2* Ts = sh + OPC * DDMAX * BT;                              // [DM][OPC][BT]
+    const long blk = blockIdx.x - g.start[p];
+    const int bl = threadIdx.x % BT, ry = threadIdx.x / BT;
+    const long s = blk * BT + bl;
+    const bool ok = s < q.P;
+    const long sc = ok ? s : q.P - 1;
+    const int nA = OPC * dD * BT;                                    // <= 512: two elements per thread
+    // (element offsets in 32 bits -- at most 32 planes of at most 2048 x 1025 bins here --, so the loads take the scalar-base +
+    // 32-bit lane offset form and the 28 addresses cost one register each; M^ is Hermitian: upper triangle only)
+    const unsigned P = (unsigned)q.P, scu = (unsigned)sc;
+    float2 ast[2], c[DDMAX], f[DM], Mu[10];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const unsigned idx = (unsigned)min(w * 256 + (int)threadIdx.x, nA - 1);
+        const unsigned kd = idx / BT, b2 = idx - kd * BT;
+        ast[w] = ld8(q.A, kd * P + min((unsigned)blk * BT + b2, P - 1));
+    }
+#pragma unroll
+    for (int d = 0; d < DDMAX; ++d) c[d] = ld8(q.C + (size_t)min(d, dD - 1) * P, (unsigned)(ry * dD) * P + scu);      // (uniform row base + one lane offset)
+    const int a = min(ry, dD - 1);
+#pragma unroll
+    for (int m = 0; m < DM; ++m) f[m] = ld8(q.F + (size_t)m * P, (unsigned)(a * DM) * P + scu);
+    {
+        const unsigned u = (unsigned)map_up(sc, q.Nx, q.Ny, g.Nx0, g.Ny0), P0 = (unsigned)g.P0;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < OPC; ++i)
+#pragma unroll
+            for (int j = i; j < OPC; ++j) Mu[e++] = ld8(g.Mhat + (size_t)(i * OPC + j) * P0, u);
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) { const int idx = w * 256 + threadIdx.x; if (idx < nA) As[idx] = ast[w]; }
+    __syncthreads();
+    const float NN = (float)q.Nx * (float)q.Ny;
+    {
+        float2 t[OPC];
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) {
+            t[k] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int d = 0; d < DDMAX; ++d) if (d < dD) cfma2(t[k], c[d], As[(k * dD + d) * BT + bl]);
+            t[k].x *= 1.0f / (float)DM; t[k].y *= 1.0f / (float)DM;
+        }
+        if (s == 0) t[OPC - 1].x += q.b[ry] * NN;
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) Ts[(ry * OPC + k) * BT + bl] = t[k];
+    }
+    __syncthreads();
+    float part = 0.f;
+    if (ry < dD) {
+        const float idD = 1.0f / (float)dD;
+        float2 r[OPC];
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) r[k] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) cfma2(r[k], f[m], Ts[(m * OPC + k) * BT + bl]);
+            if (m & 1) __builtin_amdgcn_sched_barrier(0);           // (keeps the 32 LDS reads from being hoisted into 64 live registers)
+        }
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) {
+            const float2 av = As[(k * dD + a) * BT + bl];
+            r[k] = make_float2(av.x - r[k].x * idD, av.y - r[k].y * idD);
+        }
+        if (s == 0) r[OPC - 1].x -= q.p[a] * NN;
+        // r M^ r^H = sum_k M[k][k] |r_k|^2 + 2 sum_{k<k2} Re( r_k M[k][k2] conj(r_k2) )
+        {
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) {
+                part += Mu[e++].x * (r[k].x * r[k].x + r[k].y * r[k].y);
+#pragma unroll
+                for (int k2 = k + 1; k2 < OPC; ++k2) {
+                    float2 v = make_float2(0.f, 0.f);
+                    cfmac(v, Mu[e++], r[k2]);                            // M[k][k2] conj(r_k2)
+                    part += 2.f * (r[k].x * v.x - r[k].y * v.y);
+                }
+            }
+        }
+        const int nyr = q.Ny / 2 + 1;
+        const int j = (int)((unsigned)sc % (unsigned)nyr);
+        part *= !ok ? 0.f : ((j > 0 && j < nyr - 1) ? 2.f : 1.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    float* red = reinterpret_cast<float*>(Ts + (size_t)DM * OPC * BT);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tot != 0.f) atomicAdd(q.slots + (blockIdx.x % MSE_SLOTS) * MSE_SLOT_STRIDE, tot * q.scale);
+    }
+}
+
 // The innermost pair from the bin-major copy of the updated spectra (kspec_packed_body): one workgroup per bin, C' and F' read as
 // contiguous rows (the planar layout makes them 8 K scattered 32-byte pieces per bin tile), two chain stages and the quadratic form.
 __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t)
@@ -442,7 +553,8 @@ __global__ __launch_bounds__(256) void opmse_kernel(const OpMseGroup g)
     for (int i = 6; i >= 0; --i) if (i < g.n - 1 && (int)blockIdx.x >= g.start[i]) p = i;
     if (p == g.n - 1 && g.Wp) { opmse_packed(g, p, (long)blockIdx.x - g.start[p]); return; }
     const int bt = g.bt[p];                                          // uniform per workgroup
-    if (bt == 16) opmse_body<16>(g, p, sh);
+    if (bt == 32) opmse_small_body<8>(g, p, sh);
+    else if (bt == 16) opmse_body<16>(g, p, sh);
     else if (bt == 8) opmse_body<8>(g, p, sh);
     else opmse_body<4>(g, p, sh);
 }
@@ -457,8 +569,9 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
         // bins per workgroup: whole 128-byte lines when the pair still yields >= 128 workgroups and its tiles fit 64 KB of LDS
         int bt = 16;
         while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
-        const size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2);
+        size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2);
         const bool pk = i == g.n - 1 && g.Wp && q.dD <= CH_VMAX && q.dM <= CH_VMAX;
+        if (!pk && q.dM == 8 && q.dD <= 4 && !flag(AEFFT_F_NOFAST)) { bt = 32; need = (size_t)OPC * (4 + 8) * 32 * sizeof(float2) + 64; }     // opmse_small_body (bt == 32 selects it)
         if (i == g.n - 1 && !pk) g.Wp = nullptr;
         if (need > 150 * 1024 && !pk) return hipErrorInvalidValue;
         g.bt[i] = bt;
