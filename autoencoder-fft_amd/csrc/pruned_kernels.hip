@@ -417,13 +417,13 @@ static PackArgs g_pack_none{};
 template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st, PackArgs* pk = nullptr)
 {
     int total = 0; size_t lds = 0;
-    long pb_all = 0;
-    for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); pb_all += (g.q[p].planes + g.ppb[p] - 1) / g.ppb[p]; }
+    for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); }
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
-        int chunks = 1;                                   // rows split until the LAUNCH has ~1024 workgroups (>= 8 rows each)
-        while (pb_all * chunks < 1024 && q.Nx / (chunks * 2) >= 8) chunks *= 2;
+        // <= 64 rows per workgroup for every problem (a launch-wide chunk count gave the big grids 128-row workgroups on half their
+        // lanes: 23.7 us against 21.5 us at cfg3; 32 rows: 22.0, 16 rows: 24.9)
+        const int chunks = (q.Nx + 63) / 64;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
         g.start[p] = total; total += g.pblocks[p] * chunks;
         lds = std::max(lds, kspec_lds(g.rows[p], NK));

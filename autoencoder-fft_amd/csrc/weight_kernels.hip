@@ -42,6 +42,19 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
     float* red = ws + dD * TM * KK;
     // staging in batches of 8 independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
     // one memory round trip per element otherwise)
+    auto wload = [&](int t) {
+        t = min(t, dD * TM * KK - 1);
+        const int d1 = t / (TM * KK), rem = t - d1 * (TM * KK);
+        const int m2 = min(m0 + rem / KK, dM - 1), r = rem % KK;
+        return isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
+    };
+    // the first 24 loads per thread of the weight slab go out BEFORE the Q loads: both are in flight in the same round trip
+    float wv[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) {
+        if (u * 256 >= dD * TM * KK) break;                          // uniform
+        wv[u] = wload(u * 256 + (int)threadIdx.x);
+    }
     const int nq = q.nq;
     if (nq <= 1) {
         for (int t0 = 0; t0 < dD * TT; t0 += 256 * 12) {
@@ -80,16 +93,15 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
             for (int u = 0; u < 4; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = acc4[u]; }
         }
     }
-    // (24 loads per thread in flight: the weight slab of the innermost pair is 37 loads per thread, i.e. two round trips, not five)
-    for (int t0 = 0; t0 < dD * TM * KK; t0 += 256 * 24) {
+    // the rest of the weight slab (the innermost pair's is 37 loads per thread: one more round trip, not four)
+#pragma unroll
+    for (int u = 0; u < 24; ++u) { const int t = u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = wv[u]; }
+    for (int t0 = 256 * 24; t0 < dD * TM * KK; t0 += 256 * 24) {
         float v[24];
 #pragma unroll
         for (int u = 0; u < 24; ++u) {
             if (t0 + u * 256 >= dD * TM * KK) break;                 // uniform: whole load instructions are skipped
-            const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TM * KK - 1);
-            const int d1 = t / (TM * KK), rem = t - d1 * (TM * KK);
-            const int m2 = min(m0 + rem / KK, dM - 1), r = rem % KK;
-            v[u] = isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
+            v[u] = wload(t0 + u * 256 + (int)threadIdx.x);
         }
 #pragma unroll
         for (int u = 0; u < 24; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = v[u]; }
