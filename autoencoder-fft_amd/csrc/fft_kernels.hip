@@ -21,6 +21,7 @@
 // radix-8 Stockham (decimation in frequency, auto-sort) passes with a final radix-4/2 pass,
 // data exchanged through LDS between passes (padded index n + n/8 against bank conflicts).
 #include "internal.h"
+#include "device_util.h"
 #include <math.h>
 #include <vector>
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     const long vmax = (npairs - pair0) * (2 * N / 4) - 1;      // last valid float4 of this workgroup's chunk
     float4 val[NLD];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) { const long v = tid + k * NT; val[k] = src[v <= vmax ? v : vmax]; }
+    for (int k = 0; k < NLD; ++k) { const long v = tid + k * NT; val[k] = ld_stream(&src[v <= vmax ? v : vmax]); }      // (frames are read once)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int v = tid + k * NT;
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
         const bool ok = (pair0 + gg < npairs) && k < Wc;
         const long pr = (pair0 + gg < npairs) ? pair0 + gg : npairs - 1;
         const float2* rowA = mid + (pr * 2) * Wc + (k < Wc ? k : 0);
-        av[q] = *reinterpret_cast<const float4*>(rowA);
-        bv[q] = *reinterpret_cast<const float4*>(rowA + Wc);
+        av[q] = ld_stream(reinterpret_cast<const float4*>(rowA));
+        bv[q] = ld_stream(reinterpret_cast<const float4*>(rowA + Wc));
         if (!ok) { av[q] = make_float4(0.f, 0.f, 0.f, 0.f); bv[q] = av[q]; }
     }
 #pragma unroll
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
         const int row = o / N, n0 = o % N;
         if (pair0 + gg < npairs) {
             const float* zs = reinterpret_cast<const float*>(s + gg * PL) + row;
-            dst[v] = make_float4(zs[2 * pad_idx(n0)] * scale, zs[2 * pad_idx(n0 + 1)] * scale,
-                                 zs[2 * pad_idx(n0 + 2)] * scale, zs[2 * pad_idx(n0 + 3)] * scale);
+            st_stream(&dst[v], make_float4(zs[2 * pad_idx(n0)] * scale, zs[2 * pad_idx(n0 + 1)] * scale,
+                                           zs[2 * pad_idx(n0 + 2)] * scale, zs[2 * pad_idx(n0 + 3)] * scale));     // (the images are not read again)
         }
     }
 }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int it = tid + k * NT;
-        val[k] = *reinterpret_cast<const float4*>(src + (long)(it / (CW / 2)) * Wc + 2 * (it % (CW / 2)));
+        val[k] = ld_stream(reinterpret_cast<const float4*>(src + (long)(it / (CW / 2)) * Wc + 2 * (it % (CW / 2))));     // (mid dies here)
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {

@@ -67,7 +67,7 @@ __device__ __forceinline__ void moment_body(const float2* __restrict__ Xf, float
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const int bb = min(b + f, b1 - 1);
-                x[f][d] = d < D0 ? Xf[((long)bb * D0 + d) * P0 + uc] : make_float2(0.f, 0.f);
+                x[f][d] = d < D0 ? ld_stream(&Xf[((long)bb * D0 + d) * P0 + uc]) : make_float2(0.f, 0.f);     // (the last full pass over the input spectra)
             }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {

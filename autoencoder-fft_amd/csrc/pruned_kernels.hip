@@ -221,7 +221,7 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
     float2 d[16];
     if (nrows > 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) d[u] = src[(long)min(u, nrows - 1) * Nyr];
+        for (int u = 0; u < 16; ++u) d[u] = ld_stream(&src[(long)min(u, nrows - 1) * Nyr]);      // (S is read once)
     }
     // phase tables: batches of independent gathers (a rolled load -> store loop is one L2 round trip per entry)
     for (int t0 = 0; t0 < CR * NK; t0 += NT * 4) {
@@ -247,7 +247,7 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         for (int i = 0; i < nrows; i += 16) {
             if (i > 0) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) d[u] = src[(long)min(i + u, nrows - 1) * Nyr];
+                for (int u = 0; u < 16; ++u) d[u] = ld_stream(&src[(long)min(i + u, nrows - 1) * Nyr]);
             }
             if (i + 16 > nrows) {                         // tail batch: rows past the slice were read clamped, they count zero
 #pragma unroll
