@@ -25,7 +25,7 @@ namespace aefft {
 template <int NK>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
 {
-    constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, SL = 4, TM = 256 / (NK * SL);    // 12 outer channels x 4 d1 slices per workgroup for 5x5
+    constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, SL = 8, TM = 256 / (NK * SL);    // 6 outer channels x 8 d1 slices per workgroup for 5x5 (4 slices: 18.1 us, 8: 14.2 us at cfg3)
     extern __shared__ float sh[];                       // Qs[dD][TT] | ws[dD][TM][KK] | red[256][NK]
     int p = 0;
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
 hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
 {
     if (g.n < 1 || g.n > 8 || (Nk != 3 && Nk != 5)) return hipErrorInvalidValue;
-    const int KK = Nk * Nk, TT = (2 * Nk - 1) * (2 * Nk - 1), TM = 256 / (Nk * 4);
+    const int KK = Nk * Nk, TT = (2 * Nk - 1) * (2 * Nk - 1), TM = 256 / (Nk * 8);
     int total = 0; size_t lds = 0;
     for (int i = 0; i < g.n; ++i) {
         const WgradProb& q = g.q[i];

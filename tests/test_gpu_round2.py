@@ -62,10 +62,17 @@ def test_config3_bench_batch_default_equals_literal(ctx, flags):
         n = 2 * c.size + b.size + p.size
         assert relerr(g_opt[off:off + n], g_lit[off:off + n]) < 5e-5, l
         off += n
+    off = 0
     for l, (a, b_) in enumerate(zip(w_lit, w_opt)):
-        for x, y, w0 in zip(a, b_, ws[l]):
+        c, b, f, p = ws[l]
+        segs = {}
+        for k, n in (("c", c.size), ("f", f.size), ("b", b.size), ("p", p.size)):       # packed order: dck | dfk | db | dp
+            segs[k] = np.abs(g_lit[off:off + n]).max(); off += n
+        for x, y, w0, k in zip(a, b_, ws[l], ("c", "b", "f", "p")):                     # get_pair order: c, b, f, p
             dw = np.abs(x - w0).max()
-            assert np.abs(x - y).max() < 1e-6 + 2e-3 * dw
+            # a weight moves by del * g (del = 0.02): the gradient bound above (5e-5 of the largest entry, which the clip may cut
+            # down afterwards) is what an unclipped entry's step can be off by
+            assert np.abs(x - y).max() < 1e-6 + max(2e-3 * dw, 0.02 * 5e-5 * segs[k]), (l, k)
     assert relerr(r_opt, r_lit) < 2e-5
     assert np.allclose(m_lit, m_opt, rtol=1e-4)
 
