@@ -260,3 +260,48 @@ def test_batched_layer_export_and_magnitude(ctx):
     assert relerr(got, mag) < 1e-5
     got_s = host(ctx.magnitude(ctx.dev(X), Ny, ch, shift=True))
     assert relerr(got_s, np.roll(mag, (Nx // 2, Ny // 2), axis=(-2, -1))) < 1e-5
+
+
+def test_operator_form_stays_on_the_per_frame_numbers_after_training(ctx, flags):
+    """300 operator-form steps on changing frames (the MSE falls by an order of magnitude), then ONE step of each form from those
+    weights: reconstruction, gradients and post-update MSE of the operator form are still the per-frame form's (the quadratic-form
+    MSE and the operator-level difference S have no extra cancellation at a trained state)."""
+    rng = np.random.default_rng(11)
+    D, N, maps, Nk, s, B = 3, 128, [8, 16], 5, 2, 4
+    ws = _weights(rng, D, maps, Nk)
+    frames = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(3)]
+    recon, mse = ctx.empty(B, D, N, N), ctx.empty(len(maps))
+    flags()
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(ws):
+        net.set_pair(l, *w)
+    first = None
+    for it in range(300):
+        net.step_grad(frames[it % 3], recon)
+        net.step_apply(0.02, 0, 0, 1.0, mse)
+        if it == 2:
+            ctx.sync(); first = host(mse).copy()
+    ctx.sync()
+    last = host(mse).copy()
+    assert np.isfinite(last).all() and last[0] < 0.5 * first[0]            # it trained
+    trained = [net.get_pair(l) for l in range(len(maps))]
+    net.close()
+    res = []
+    for fl in ([], ["NOOPFORM"]):
+        flags(*fl)
+        n2 = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(trained):
+            n2.set_pair(l, *w)
+        n2.step_grad(frames[0], recon)
+        g = host(n2.grad_buffer()).copy()
+        n2.step_apply(0.02, 0, 0, 1.0, mse)
+        res.append((g, host(recon).copy(), host(mse).copy()))
+        n2.close()
+    (g_op, r_op, m_op), (g_pf, r_pf, m_pf) = res
+    assert relerr(r_op, r_pf) < 2e-5
+    off = 0
+    for c, b, f, p in trained:
+        n = 2 * c.size + b.size + p.size
+        assert relerr(g_op[off:off + n], g_pf[off:off + n]) < 5e-5
+        off += n
+    assert np.allclose(m_op, m_pf, rtol=1e-4)
