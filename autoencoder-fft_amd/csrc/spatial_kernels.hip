@@ -147,6 +147,128 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// dconv4_kernel<TM,NK>: the few-map form (M <= 4: the decoder's last layer, 50 -> 3 maps).  Too few maps for the matrix cores
+// (a 32-map MFMA tile would be 90 % padding) and, in dconv_kernel, one LDS read plus TM scalar weight loads per TM FMAs: the
+// scalar loads share the LDS wait counter, so every input read waits for them.  Here a thread owns 4 consecutive pixels of a
+// row x TM maps: per (channel, tap row) it reads its 4+NK-1 inputs (16-byte aligned vector reads) and the NK*TM weights of the
+// row from an LDS slab (broadcast reads), for 4*NK*TM FMAs -- (2 + NK*TM/4) LDS instructions per 4*NK*TM FMAs instead of
+// NK*(1 LDS + TM scalar).  Workgroup = 16 rows x 64 columns of one frame.  Same staging, tests and summation order (d, k, l).
+// ------------------------------------------------------------------------------------------
+template <int TM, int NK, bool SUB>
+__global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
+{
+    constexpr int PX = 4, TC = 16 * PX, TWY = 16 + NK - 1, TWX = ((TC + NK - 1) + 3) & ~3, DC = 4, TSZ = TWY * TWX;
+    constexpr int NLD = (DC * TSZ + 255) / 256;           // staged elements per thread and stage
+    constexpr int WS = (NK * TM + 3) & ~3;                // weights of one (channel, tap row): [l][t], padded to whole float4
+    __shared__ __attribute__((aligned(16))) float tile[DC][TSZ];
+    extern __shared__ __attribute__((aligned(16))) float wl[];     // [Din][NK][WS]: ALL weights of this workgroup's maps, staged once
+    const int tiles_y = (a.Ny + TC - 1) / TC;
+    const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
+    const int m0 = blockIdx.y * TM;
+    const long bb = blockIdx.z;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int i = ti * 16 + ty, j0 = tj * TC + tx * PX;
+    for (int t = threadIdx.x; t < a.Din * NK * NK * TM; t += 256) {      // (maps past M read the last map: their sums are never stored)
+        const int tm = t % TM, l = (t / TM) % NK, k = (t / (TM * NK)) % NK, d = t / (TM * NK * NK);
+        const int m = min(m0 + tm, a.M - 1);
+        // stored at the tile offset the tap reads (sgn < 0: input index = output index - tap offset, i.e. the taps run backwards
+        // over the tile), so that the compute loop indexes its registers with compile-time constants
+        const int kk = a.sgn < 0 ? NK - 1 - k : k, ll = a.sgn < 0 ? NK - 1 - l : l;
+        wl[(d * NK + kk) * WS + ll * TM + tm] = a.w[(long)m * a.w_m + (long)d * a.w_d + k * NK + l];
+    }
+    const int r0 = a.sgn < 0 ? ti * 16 - a.ik0 - (NK - 1) : ti * 16 + a.ik0;
+    const int c0 = a.sgn < 0 ? tj * TC - a.il0 - (NK - 1) : tj * TC + a.il0;
+    const long plane = (long)a.Nx * a.Ny;
+    // this thread's staged elements: offset inside a stage's DC planes (the same for every stage) and whether the element exists
+    int off[NLD]; unsigned okm = 0, dlq[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int t = u * 256 + threadIdx.x;
+        const int dl = min(t / TSZ, DC - 1), q = t % TSZ;
+        const int r = r0 + q / TWX, cc = c0 + q % TWX;
+        const bool ok = t < DC * TSZ && r >= a.lo_in && r < a.Nx && cc >= a.lo_in && cc < a.Ny;
+        off[u] = ok ? dl * (int)plane + r * a.Ny + cc : 0;
+        okm |= (ok ? 1u : 0u) << u;
+        dlq[u] = (unsigned)dl;
+    }
+    float acc[TM][PX];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[t][p] = 0.f;
+    float v[NLD], v2[SUB ? NLD : 1];
+    auto prefetch = [&](int d0) {                          // the next stage's inputs: in flight while this stage computes
+        const int nd = min(DC, a.Din - d0);
+        const float* base = a.in + (bb * a.Din + d0) * plane;
+        const float* base2 = SUB ? a.in2 + (bb * a.Din + d0) * plane : nullptr;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const bool ok = ((okm >> u) & 1u) && (int)dlq[u] < nd;
+            v[u] = base[ok ? off[u] : 0];
+            if (SUB) v2[u] = base2[ok ? off[u] : 0];
+            if (!ok) { v[u] = 0.f; if (SUB) v2[u] = 0.f; }
+        }
+    };
+    prefetch(0);
+    for (int d0 = 0; d0 < a.Din; d0 += DC) {
+        const int nd = min(DC, a.Din - d0);
+        __syncthreads();                                  // the previous stage's reads are done
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int t = u * 256 + threadIdx.x;
+            if (t < DC * TSZ) {
+                float x = SUB ? v[u] - v2[u] : v[u];
+                if (a.div != 1.f) x = x / a.div;
+                tile[0][t] = x;
+            }
+        }
+        __syncthreads();
+        if (d0 + DC < a.Din) prefetch(d0 + DC);
+        for (int dl = 0; dl < nd; ++dl) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const float* xr = &tile[dl][(ty + k) * TWX + tx * PX];     // (k, l: tile offsets, see the weight slab)
+                float x[PX + NK - 1];
+                {
+                    const float4 x4 = *reinterpret_cast<const float4*>(xr);
+                    x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
+#pragma unroll
+                    for (int e = PX; e < PX + NK - 1; ++e) x[e] = xr[e];
+                }
+                float w[WS];
+#pragma unroll
+                for (int e = 0; e < WS; e += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(&wl[((d0 + dl) * NK + k) * WS + e]);
+                    w[e] = w4.x; w[e + 1] = w4.y; w[e + 2] = w4.z; w[e + 3] = w4.w;
+                }
+#pragma unroll
+                for (int l = 0; l < NK; ++l)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int p = 0; p < PX; ++p) acc[t][p] = fmaf(w[l * TM + t], x[p + l], acc[t][p]);
+            }
+        }
+    }
+    if (i >= a.Nx) return;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int m = m0 + t;
+        if (m >= a.M) break;
+        const float bs = a.bias ? a.bias[m] : 0.f;
+        float* dst = a.out + (bb * a.M + m) * plane + (long)i * a.Ny + j0;
+        float o[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) o[p] = (i < a.hi_lo || j0 + p < a.hi_lo) ? 0.f : acc[t][p] + bs;
+        if (j0 + PX <= a.Ny && (a.Ny & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) if (j0 + p < a.Ny) dst[p] = o[p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // mconv_kernel<MB,NK>: the same convolution as an IMPLICIT GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
 //     out[m][pixel] = sum_{(d,k,l)} w[m][(d,k,l)] * in[d][pixel shifted by (k,l)]        M = maps, N = pixels, K = Din*NK*NK
 // A = weights (rows = 32 maps of a block, k = 2 consecutive (d,k,l) indices), B = input pixels (cols = 32 pixels of one tile row,
@@ -295,6 +417,18 @@ template <int NK> static hipError_t run_mconv(const DConvArgs& a, int B, hipStre
 
 template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStream_t st)
 {
+    if (a.M <= 4 && a.Ny >= 64 && (long)a.Nx * a.Ny * 4 < (1L << 31) && (size_t)a.Din * NK * ((NK * 4 + 3) & ~3) * 4 <= 32 * 1024 && !flag(AEFFT_F_NOFAST)) {        // few maps, wide planes: the register-blocked form
+        const int tiles4 = ((a.Nx + 15) / 16) * ((a.Ny + 63) / 64);
+#define AEFFT_D4(TMV) { const size_t wb = sizeof(float) * (size_t)a.Din * NK * ((NK * TMV + 3) & ~3);                            \
+            if (a.in2) dconv4_kernel<TMV, NK, true><<<dim3(tiles4, 1, B), 256, wb, st>>>(a);                                      \
+            else dconv4_kernel<TMV, NK, false><<<dim3(tiles4, 1, B), 256, wb, st>>>(a); }
+        if (a.M == 4) AEFFT_D4(4)
+        else if (a.M == 3) AEFFT_D4(3)
+        else if (a.M == 2) AEFFT_D4(2)
+        else AEFFT_D4(1)
+#undef AEFFT_D4
+        return hipGetLastError();
+    }
     const int tiles = ((a.Nx + 15) / 16) * ((a.Ny + 15) / 16);
     if (a.M >= 12) dconv_kernel<16, NK><<<dim3(tiles, (a.M + 15) / 16, B), 256, 0, st>>>(a);
     else if (a.M >= 6) dconv_kernel<8, NK><<<dim3(tiles, (a.M + 7) / 8, B), 256, 0, st>>>(a);
