@@ -74,6 +74,7 @@ struct DConvArgs {
     // and every staged input pixel is max(0, trunc(max of its pool x pool window)); pooled_out (nullable) also receives the pooled
     // layer [B][Din][Nx][Ny] (the training step needs it as the pair's input).  pool == 0: off.
     int pool; float* pooled_out;
+    int nt_out;                 // (set by launch_dconv) the output is larger than the Infinity Cache: streaming stores
 };
 
 template <int TM, int NK>
@@ -293,9 +294,11 @@ __global__ __launch_bounds__(256) void mconv_kernel(const DConvArgs a)
     constexpr int DC = Cfg::DC, KK = Cfg::KK, KCP = Cfg::KCP, MT = 32 * MB;
     __shared__ float tile[DC][TSZ];
     __shared__ float wl[KCP][MT];
+    __shared__ float bsl[MT];                               // the block's biases (read 16*MB times per lane by the epilogue)
     const int tiles_y = (a.Ny + TC - 1) / TC;
     const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
     const int m0 = blockIdx.y * MT;
+    if ((int)threadIdx.x < MT) bsl[threadIdx.x] = (a.bias && m0 + (int)threadIdx.x < a.M) ? a.bias[m0 + threadIdx.x] : 0.f;
     const long bb = blockIdx.z;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, kq = lane >> 5;
@@ -400,9 +403,12 @@ __global__ __launch_bounds__(256) void mconv_kernel(const DConvArgs a)
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * mb + (e & 3) + 8 * (e >> 2) + 4 * kq;
-                if (m >= a.M) continue;
-                a.out[(bb * a.M + m) * plane + (long)i * a.Ny + j] = zero ? 0.f : acc[r][mb][e] + (a.bias ? a.bias[m] : 0.f);
+                const int ml = 32 * mb + (e & 3) + 8 * (e >> 2) + 4 * kq;
+                if (m0 + ml >= a.M) continue;
+                const float o = zero ? 0.f : acc[r][mb][e] + bsl[ml];
+                float* dst = &a.out[(bb * a.M + m0 + ml) * plane + (long)i * a.Ny + j];
+                if (a.nt_out) __builtin_nontemporal_store(o, dst);      // (uniform) a layer larger than the caches: do not displace its own input
+                else *dst = o;
             }
     }
 }
@@ -436,8 +442,10 @@ template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStre
     return hipGetLastError();
 }
 static bool dconv_ok(int Nk, int Nl, int B) { return Nk == Nl && (Nk == 3 || Nk == 5 || Nk == 7) && B <= 65535; }
-static hipError_t launch_dconv(const DConvArgs& a, int Nk, int B, hipStream_t st)
+static hipError_t launch_dconv(const DConvArgs& a0, int Nk, int B, hipStream_t st)
 {
+    DConvArgs a = a0;
+    a.nt_out = (double)B * a.M * a.Nx * a.Ny * 4.0 > 192e6;
     // matrix cores whenever there is a GEMM to speak of (>= 8 maps); AEFFT_F_NOMFMA keeps the VALU tile kernel (and the fused
     // Pool exists only in the matrix-core kernel)
     if ((a.M >= 8 && !flag(AEFFT_F_NOMFMA)) || a.pool) {
