@@ -203,12 +203,13 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
                                                   int bx, int chunk, float2* lds)
 {
     constexpr int TS = NT + 1;                                      // row stride of the t arrays (+1: the NK rows land in different banks)
-    constexpr int TT = NK * NL;
+    constexpr int TT = NK * NL, H = NK / 2;
+    static_assert(NK % 2 == 1, "symmetric offsets");
     const int Nyr = Ny / 2 + 1;
     const int CR = S * RB;                                          // rows of this chunk (the last one may hold fewer)
     const int r0 = chunk * CR, crow = min(CR, Nx - r0);
-    float2* rowph = lds;                                            // [CR][NK]   e^{+2 pi i i kap_k / Nx}
-    float2* colph = rowph + CR * NK;                                // [Nyr][NL]  e^{+2 pi i j lam_l / Ny}
+    float2* rowph = lds;                                            // [CR][H]    e^{+2 pi i i kap / Nx}, kap = 1 .. H
+    float2* colph = rowph + CR * H;                                 // [Nyr][NL]  e^{+2 pi i j lam_l / Ny}
     float* tre = reinterpret_cast<float*>(colph + Nyr * NL);        // [NK][TS]   per-thread row sums t_k (real part)
     float* tim = tre + NK * TS;                                     // [NK][TS]
     const int per = ppb * Nyr;
@@ -224,12 +225,13 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         for (int u = 0; u < 16; ++u) d[u] = ld_stream(&src[(long)min(u, nrows - 1) * Nyr]);      // (S is read once)
     }
     // phase tables: batches of independent gathers (a rolled load -> store loop is one L2 round trip per entry)
-    for (int t0 = 0; t0 < CR * NK; t0 += NT * 4) {
+    // (row phases of the H = NK/2 positive offsets only: the phase of -kap is the conjugate)
+    for (int t0 = 0; t0 < CR * H; t0 += NT * 4) {
         float2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, CR * NK - 1); v[u] = phase(tw, (r0 + t / NK) & (Nx - 1), t % NK - NK / 2, Nx, -1.f); }
+        for (int u = 0; u < 4; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, CR * H - 1); v[u] = phase(tw, (r0 + t / H) & (Nx - 1), t % H + 1, Nx, -1.f); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < CR * NK) rowph[t] = v[u]; }
+        for (int u = 0; u < 4; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < CR * H) rowph[t] = v[u]; }
     }
     for (int t0 = 0; t0 < Nyr * NL; t0 += NT * 5) {
         float2 v[5];
@@ -239,11 +241,16 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         for (int u = 0; u < 5; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < Nyr * NL) colph[t] = v[u]; }
     }
     __syncthreads();
+    // t_k = sum_i d_i e^{+i th_k(i)} for the offsets kap = k - H.  The offsets come in conjugate pairs: d*p and d*conj(p) share their
+    // four products, so per pair the sums A = sum dx px, B = sum dy py, C = sum dx py, E = sum dy px are accumulated (4 FMAs per
+    // element instead of 8) and t_{+kap} = (A - B, C + E), t_{-kap} = (A + B, E - C) at the end; kap = 0 is the plain sum.
     float2 t[NK];
+    float2 s0 = make_float2(0.f, 0.f);
+    float pa[H > 0 ? H : 1], pb[H > 0 ? H : 1], pc[H > 0 ? H : 1], pe[H > 0 ? H : 1];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) t[k] = make_float2(0.f, 0.f);
+    for (int k = 0; k < H; ++k) pa[k] = pb[k] = pc[k] = pe[k] = 0.f;
     if (nrows > 0) {
-        const float2* rp0 = rowph + i0 * NK;
+        const float2* rp0 = rowph + i0 * H;
         for (int i = 0; i < nrows; i += 16) {
             if (i > 0) {
 #pragma unroll
@@ -255,15 +262,22 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const float2* rp = rp0 + min(i + u, nrows - 1) * NK;
+                const float2* rp = rp0 + min(i + u, nrows - 1) * H;
+                s0.x += d[u].x; s0.y += d[u].y;
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
+                for (int k = 0; k < H; ++k) {
                     const float2 r = rp[k];
-                    t[k].x += d[u].x * r.x - d[u].y * r.y;
-                    t[k].y += d[u].x * r.y + d[u].y * r.x;
+                    pa[k] = fmaf(d[u].x, r.x, pa[k]); pb[k] = fmaf(d[u].y, r.y, pb[k]);
+                    pc[k] = fmaf(d[u].x, r.y, pc[k]); pe[k] = fmaf(d[u].y, r.x, pe[k]);
                 }
             }
         }
+    }
+    t[H] = s0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        t[H + 1 + k] = make_float2(pa[k] - pb[k], pc[k] + pe[k]);
+        t[H - 1 - k] = make_float2(pa[k] + pb[k], pe[k] - pc[k]);
     }
     if (active) {
 #pragma unroll
