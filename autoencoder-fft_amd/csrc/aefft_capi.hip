@@ -2019,10 +2019,10 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
         ctx->recon_join = true;
     }
     if (n->recon_pending) {
-        // joined where the deferred form is: by aefft_net_step_apply (after its last launch), aefft_sync or the next call on this
-        // net -- nothing the update half launches touches what the reconstruction reads or writes
+        // the documented default: recon_d is complete, in stream order on the context stream, when this call's work is
+        // (include/aefft.h; the pipelined mode relaxes it).  Joining later -- behind the update half -- was measured: see DESIGN.md 6.
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-        ctx->recon_join = true;
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
         n->recon_pending = false;
     }
     n->have_grad = true;

@@ -293,34 +293,43 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         }
     }
     __syncthreads();
-    // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ): the columns of a plane are split over JS threads per output
-    // (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums combined in slice order
-    const int nout = ppb * TT;
-    int JS = NT / nout;
+    // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ).  The column offsets come in conjugate pairs as well: a task is
+    // (plane, k, |lam|) and accumulates P = sum w tre cx and Q = sum w tim cy, g[+lam] = P - Q, g[-lam] = P + Q.  The columns of a
+    // plane are split over JS threads per task (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums
+    // combined in slice order.
+    constexpr int HL = NL / 2, TK = NK * (HL + 1);
+    static_assert(NL % 2 == 1, "symmetric offsets");
+    const int nout = ppb * TT, ntask = ppb * TK;
+    int JS = NT / ntask;
     if (JS < 1) JS = 1;
     if (JS > 16) JS = 16;
     const int jlen = (Nyr + JS - 1) / JS;
-    float* part = tim + NK * TS;                          // [nout][JS], after the t arrays
-    for (int it = threadIdx.x; it < nout * JS; it += NT) {
+    float* part = tim + NK * TS;                          // [ntask][JS][2], after the t arrays
+    for (int it = threadIdx.x; it < ntask * JS; it += NT) {
         const int o = it / JS, js = it - o * JS;
-        const int p2 = o / TT, kl = o - p2 * TT;
-        const int k = kl / NL, l = kl - k * NL;
-        float a = 0.f;
+        const int p2 = o / TK, kl = o - p2 * TK;
+        const int k = kl / (HL + 1), lam = kl - k * (HL + 1);
+        float pp = 0.f, qq = 0.f;
         const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
         for (int jj = j0; jj < j1; ++jj) {
-            const float2 cp = colph[jj * NL + l];
+            const float2 cp = colph[jj * NL + HL + lam];
             const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
-            a += wj * (tre[k * TS + p2 * Nyr + jj] * cp.x - tim[k * TS + p2 * Nyr + jj] * cp.y);
+            pp = fmaf(wj * tre[k * TS + p2 * Nyr + jj], cp.x, pp);
+            qq = fmaf(wj * tim[k * TS + p2 * Nyr + jj], cp.y, qq);
         }
-        part[it] = a;
+        part[2 * it] = pp; part[2 * it + 1] = qq;
     }
     __syncthreads();
     for (int o = threadIdx.x; o < nout; o += NT) {
         const int p2 = o / TT, kl = o - p2 * TT;
         const long pln = (long)bx * ppb + p2;
         if (pln >= planes) continue;
+        const int k = kl / NL, l = kl - k * NL;
+        const int lam = l >= HL ? l - HL : HL - l;
+        const float sg = l >= HL ? -1.f : 1.f;
+        const float* pt = part + 2 * ((p2 * TK + k * (HL + 1) + lam) * JS);
         float a = 0.f;
-        for (int js = 0; js < JS; ++js) a += part[o * JS + js];
+        for (int js = 0; js < JS; ++js) a += pt[2 * js] + sg * pt[2 * js + 1];
         g[(pln * nchunks + chunk) * TT + kl] = a * scale;       // [plane][chunk][tap]: the consumer adds the chunks in order
     }
 }
@@ -491,7 +500,7 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
         const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::max(1, g.chunks[p]));     // in: room at dst; out: chunks used
         g.ppb[p] = k.ppb; g.rows[p] = k.S; g.rb[p] = k.RB; g.chunks[p] = k.chunks; g.pblocks[p] = k.pblocks;
         g.start[p] = total; total += k.pblocks * k.chunks;
-        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + (size_t)std::max(NT, k.ppb * NK * NL)));
+        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)std::max(NT, k.ppb * NK * NL)));
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
