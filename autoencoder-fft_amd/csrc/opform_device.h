@@ -56,8 +56,10 @@ static inline int pack_yblocks(const PackArgs& g) { return (g.NyC / 2 + 1) * ((g
 template <int NK>
 __device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int by)
 {
-    constexpr int RG = PACK_RG, KK = NK * NK;
-    __shared__ float2 ph[RG + 1][NK];                              // row phases of the RG rows, then the column's, on this tensor's grid
+    constexpr int RG = PACK_RG, KK = NK * NK, H = NK / 2;
+    static_assert(NK % 2 == 1, "symmetric tap offsets");
+    __shared__ float2 ph[RG + 1][H > 0 ? H : 1];                   // row phases of the RG rows, then the column's: offsets 1 .. H (the
+                                                                   // phase of a negative offset is the conjugate: kspec_body)
     __shared__ float taps[256 * KK];                               // the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
     const PackSeg sd = g.seg[g.blk_seg[bx]];               // (uniform: a workgroup's elements belong to ONE tensor)
     const int l0 = g.blk_start[bx];                        // first element of the block inside the tensor
@@ -72,38 +74,49 @@ __device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int
 #pragma unroll
         for (int w = 0; w < KK; ++w) v[w] = src[min(w * 256 + (int)threadIdx.x, nf - 1)];
         float2 pv = make_float2(0.f, 0.f);                         // (the phase gathers ride in the same round trip)
-        if (threadIdx.x < (RG + 1) * NK) {
-            const int k = threadIdx.x % NK, r = threadIdx.x / NK;
+        if (threadIdx.x < (RG + 1) * H) {
+            const int k = threadIdx.x % H, r = threadIdx.x / H;
             const int NxB = g.Nx[sd.lev], NyB = g.Ny[sd.lev];
-            pv = r < RG ? phase_tw(g.tw, map_up_row(min(i0 + r, g.NxC - 1), g.NxC, NxB), k - NK / 2, NxB)
-                        : phase_tw(g.tw, map_up_col(j, g.NyC, NyB), k - NK / 2, NyB);
+            pv = r < RG ? phase_tw(g.tw, map_up_row(min(i0 + r, g.NxC - 1), g.NxC, NxB), k + 1, NxB)
+                        : phase_tw(g.tw, map_up_col(j, g.NyC, NyB), k + 1, NyB);
         }
 #pragma unroll
         for (int w = 0; w < KK; ++w) { const int f = w * 256 + threadIdx.x; if (f < nf) taps[f] = v[w]; }
-        if (threadIdx.x < (RG + 1) * NK) ph[threadIdx.x / NK][threadIdx.x % NK] = pv;
+        if (threadIdx.x < (RG + 1) * H) ph[threadIdx.x / H][threadIdx.x % H] = pv;
     }
     __syncthreads();
     if (!wk || (int)threadIdx.x >= nel) return;
     const int e = sd.off + l0 + threadIdx.x;
-    float2 v[NK];
+    float2 v0, sv[H > 0 ? H : 1], dv[H > 0 ? H : 1];
     {
-        float2 cp[NK];
-#pragma unroll
-        for (int l = 0; l < NK; ++l) cp[l] = ph[RG][l];
+        const float* c = taps + threadIdx.x * KK;
+        float2 v[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            v[k] = make_float2(0.f, 0.f);
+            v[k] = make_float2(c[k * NK + H], 0.f);
 #pragma unroll
-            for (int l = 0; l < NK; ++l) v[k] = v[k] + pk_scale(taps[threadIdx.x * KK + k * NK + l], cp[l]);
+            for (int l = 0; l < H; ++l) {
+                const float2 cp = ph[RG][l];
+                const float cpl = c[k * NK + H + 1 + l], cmi = c[k * NK + H - 1 - l];
+                v[k].x = fmaf(cpl + cmi, cp.x, v[k].x);
+                v[k].y = fmaf(cpl - cmi, cp.y, v[k].y);
+            }
         }
+        v0 = v[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { sv[k] = v[H + 1 + k] + v[H - 1 - k]; dv[k] = v[H + 1 + k] - v[H - 1 - k]; }
     }
     float2* dst = g.Wp + ((long)i0 * nyrc + j) * g.E + e;
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
         if (i0 + r >= g.NxC) break;
-        float2 acc = make_float2(0.f, 0.f);
+        float2 acc = v0;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) acc = acc + pk_cmul(v[k], ph[r][k]);
+        for (int k = 0; k < H; ++k) {
+            const float2 rp = ph[r][k];
+            acc.x = fmaf(rp.x, sv[k].x, acc.x); acc.x = fmaf(-rp.y, dv[k].y, acc.x);
+            acc.y = fmaf(rp.y, dv[k].x, acc.y); acc.y = fmaf(rp.x, sv[k].y, acc.y);
+        }
         dst[(long)r * nyrc * g.E] = acc;
     }
 }

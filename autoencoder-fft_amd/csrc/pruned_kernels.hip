@@ -40,33 +40,51 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
                                                     const float2* __restrict__ tw, long planes, int Nx, int Ny,
                                                     int rows_per_chunk, int ppb, int bx, int by, float2* lds)
 {
+    // The tap offsets are symmetric (kap = -H .. H, lam = -HL .. HL) and the phase of -kap is the conjugate of kap's, so a pair of
+    // taps shares its phase:  c+ e + c- conj(e) = (c+ + c-) ex + i (c+ - c-) ey  (column factor, real taps: 2 FMAs per pair),
+    // v+ p + v- conj(p) = (px sx - py dy) + i (py dx + px sy)  with s = v+ + v-, d = v+ - v-  (row sum: 4 FMAs per pair instead of 8,
+    // one phase read instead of two).  s and d are formed once per thread: the column factor does not depend on the row.
+    constexpr int H = NK / 2, HL = NL / 2;
+    static_assert(NK % 2 == 1 && NL % 2 == 1, "symmetric tap offsets");
     const int Nyr = Ny / 2 + 1;
-    float2* rowph = lds;                                 // [rows_per_chunk][NK]
+    float2* rowph = lds;                                 // [rows_per_chunk][H]: offsets 1 .. H
     const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
-    for (int t = threadIdx.x; t < nrows * NK; t += blockDim.x) rowph[t] = phase(tw, i0 + t / NK, t % NK - NK / 2, Nx, 1.f);
+    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase(tw, i0 + t / H, t % H + 1, Nx, 1.f);
     __syncthreads();
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
     const long plane = (long)bx * ppb + pl;
     if (pl >= ppb || plane >= planes) return;
-    float2 v[NK];
+    float2 v0, sv[H > 0 ? H : 1], dv[H > 0 ? H : 1];
     {
-        float2 cp[NL];
+        float2 cp[HL > 0 ? HL : 1];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) cp[l] = phase(tw, j, l - NL / 2, Ny, 1.f);
+        for (int l = 0; l < HL; ++l) cp[l] = phase(tw, j, l + 1, Ny, 1.f);
         const float* c = kern + plane * NK * NL;
+        float2 v[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            v[k] = make_float2(0.f, 0.f);
+            v[k] = make_float2(c[k * NL + HL], 0.f);
 #pragma unroll
-            for (int l = 0; l < NL; ++l) v[k] = v[k] + pk_scale(c[k * NL + l], cp[l]);
+            for (int l = 0; l < HL; ++l) {
+                const float cpl = c[k * NL + HL + 1 + l], cmi = c[k * NL + HL - 1 - l];
+                v[k].x = fmaf(cpl + cmi, cp[l].x, v[k].x);
+                v[k].y = fmaf(cpl - cmi, cp[l].y, v[k].y);
+            }
         }
+        v0 = v[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { sv[k] = v[H + 1 + k] + v[H - 1 - k]; dv[k] = v[H + 1 + k] - v[H - 1 - k]; }
     }
     float2* dst = K + (plane * Nx + i0) * (long)Nyr + j;
     for (int i = 0; i < nrows; ++i) {
-        float2 acc = make_float2(0.f, 0.f);
+        float2 acc = v0;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) acc = acc + pk_cmul(v[k], rowph[i * NK + k]);
+        for (int k = 0; k < H; ++k) {
+            const float2 rp = rowph[i * H + k];
+            acc.x = fmaf(rp.x, sv[k].x, acc.x); acc.x = fmaf(-rp.y, dv[k].y, acc.x);
+            acc.y = fmaf(rp.y, dv[k].x, acc.y); acc.y = fmaf(rp.x, sv[k].y, acc.y);
+        }
         dst[(long)i * Nyr] = acc;
     }
 }
