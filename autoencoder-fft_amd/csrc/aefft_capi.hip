@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}};
 static void flags_from_env_once()
 {
     static bool done = false;
@@ -1200,8 +1200,13 @@ static int build_chain_items(aefft_net* n)
     if (pk) {
         PackArgs& pa = n->pack;
         int off = 0, ns = 0;
-        for (int l = 0; l < L; ++l) { const Pair& q = n->pr[l]; pa.seg[ns++] = PackSeg{q.c, q.dM * q.dD, l, off}; off += (q.dM * q.dD + 1) & ~1; }
-        for (int l = L - 1; l >= 0; --l) { const Pair& q = n->pr[l]; pa.seg[ns++] = PackSeg{q.f, q.dM * q.dD, l, off}; off += (q.dM * q.dD + 1) & ~1; }
+        // (with each tensor the gradient and momentum of the same taps: a fused update reads the taps through them, TapUpd)
+        for (int l = 0; l < L; ++l) { const Pair& q = n->pr[l]; pa.seg[ns++] = PackSeg{q.c, q.dM * q.dD, l, off, n->grad + q.goff, q.Dc}; off += (q.dM * q.dD + 1) & ~1; }
+        for (int l = L - 1; l >= 0; --l) {
+            const Pair& q = n->pr[l];
+            pa.seg[ns++] = PackSeg{q.f, q.dM * q.dD, l, off, n->grad + q.goff + (size_t)q.dM * q.dD * q.Nk * q.Nl, q.Df};
+            off += (q.dM * q.dD + 1) & ~1;
+        }
         pa.nseg = ns; pa.L = L; pa.E = off; pa.Nk = n->pr[0].Nk;
         for (int l = 0; l < L; ++l) { pa.Nx[l] = n->pr[l].Nx; pa.Ny[l] = n->pr[l].Ny; }
         pa.NxC = n->pr[L - 1].Nx; pa.NyC = n->pr[L - 1].Ny; pa.Pc = n->pr[L - 1].P; pa.tw = n->ctx->tw;
@@ -1810,6 +1815,8 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
     n->packed_valid = false;
     const bool nogroup1 = flag(AEFFT_F_NOGROUP);
+    bool fused_upd = false;                                                // the tap half of the update rides with mse_finish (below)
+    UpdateGroup wupd{};
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
         const Pair& q = n->pr[l];
@@ -1830,7 +1837,25 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
         }
         ug.n = pg.n = n->L;
-        {
+        const bool ride = n->op_state && n->Wp != nullptr;                  // the bin-major copy for the next step's chain: same taps, same launch
+        // Fused update (operator form, plain gradients): no update launch.  The spectra launch reads every tap THROUGH the pending
+        // update (w - clip_step(g, D): TapUpd) and carries the bias half as a trailing workgroup per pair; the taps and their momentum
+        // are stored in place by trailing workgroups of the step's last launch (mse_finish) -- nothing in between reads them.
+        fused_upd = ride && !sym && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
+        BiasUpdGroup bu{};
+        if (fused_upd) {
+            for (int l = 0; l < n->L; ++l) {
+                Pair& q = n->pr[l];
+                float* g = n->grad + q.goff;
+                const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
+                pg.upd[l] = TapUpd{g, q.Dc, ug.a[l].del, ug.a[l].alpha, ug.a[l].gscale};        // (c|f, dck|dfk, Dc|Df: each pair contiguous)
+                bu.a[l] = BiasUpd{q.b, q.p, q.Db, q.Dp, g + 2 * nk, g + 2 * nk + q.dM, n->mse_post + l, q.dM, q.dD};
+            }
+            bu.n = n->L; bu.del = ug.a[0].del; bu.alpha = ug.a[0].alpha; bu.gscale = ug.a[0].gscale;
+            n->pack.upd = 1; n->pack.upd_del = ug.a[0].del; n->pack.upd_alpha = ug.a[0].alpha; n->pack.upd_gscale = ug.a[0].gscale;
+            wupd = ug;
+        } else {
+            n->pack.upd = 0;
             Bracket br(ctx, KID_UPDATE, ubytes);
             hipError_t e = launch_update_group(ug, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
@@ -1838,13 +1863,18 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         hipError_t e;
         {
             Bracket br(ctx, KID_KSPEC, kbytes + ((n->op_state && n->Wp) ? (double)n->pack.Pc * n->pack.E * 8.0 : 0.0));
-            const bool ride = n->op_state && n->Wp != nullptr;              // the bin-major copy for the next step's chain: same taps, same launch
-            e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr);
+            e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr, fused_upd ? &bu : nullptr);
             if (e == hipSuccess && ride) n->packed_valid = true;
         }
+        n->pack.upd = 0;
         if (e != hipSuccess) {
             if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kspec(group)", e);
             (void)hipGetLastError();
+            if (fused_upd) {                                               // declined before anything ran: the separate update after all
+                fused_upd = false;
+                hipError_t e2 = launch_update_group(ug, ctx->cur);
+                if (e2 != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e2);
+            }
             for (int l = 0; l < n->L; ++l) RET_IF(pair_spectra(n, n->pr[l]));
         }
     } else for (int l = 0; l < n->L; ++l) {
@@ -1878,10 +1908,11 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "opmse", e);
         }
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, fused_upd ? &wupd : nullptr);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
         return AEFFT_OK;
     }
+    if (fused_upd) return fail(ctx, AEFFT_ESTATE, "apply: fused update without the operator-form tail");      // (cannot happen: fused_upd implies op_state)
     // post-update MSE (fft_backproplib.cu:1460-1463): G = F.C of every eligible pair in one launch, then every pair's pass
     // over X with the MSE epilogue in one launch; pairs the fused form does not serve (dD == 1, B == 1) go pair by pair
     std::vector<char> g_in_S(n->L, 0);       // pair l: S holds G of the updated weights after this call

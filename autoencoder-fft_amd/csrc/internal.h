@@ -73,8 +73,9 @@ struct Contract {
 };
 enum { MSE_SLOTS = 256, MSE_SLOT_STRIDE = 16 };
 struct BetaArgs { float* beta; const float2* F; const float *b, *p; int dM, dD; long P; };     // beta == null: off
+struct UpdateGroup;
 hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st,
-                             const BetaArgs* beta = nullptr);
+                             const BetaArgs* beta = nullptr, const UpdateGroup* weights_upd = nullptr /* the tap half of a fused update as trailing workgroups */);
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 // Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):
@@ -109,15 +110,22 @@ hipError_t launch_kgrad(const float2* D, float* g, float* part /*workspace: kgra
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
 // The same transforms for up to 8 problems with equal (Nk, Nl) in ONE launch (kgrad: no row chunks, so no ksum pass).
 struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale; };
+// forward pruned transform only: the taps are read THROUGH the pending clipped-momentum update (w - clip_step(g*gscale, D)), which
+// another launch stores afterwards (update_device.h) -- g == null: taps as stored
+struct TapUpd { const float* g; const float* D; float del, alpha, gscale; };
+struct BiasUpd { float *b, *p, *Db, *Dp; const float *db, *dp; float* zero; int dM, dD; };
+struct BiasUpdGroup { BiasUpd a[8]; int n; float del, alpha, gscale; };      // n == 0: none
 struct PrunedGroup {
     PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8];
+    TapUpd upd[8];
     // grouped inverse transform only: rows per slice; chunks[p] in: row chunks dst has room for ([planes][chunks][taps], 0/1 = none),
     // out: the chunks the launch used (the consumer adds them in order)
     int rb[8], chunks[8];
 };
 int kgrad_group_chunks(long planes, int Nx, int Ny);
 struct PackArgs;
-hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed = nullptr /* the bin-major copy rides along as extra workgroups */);
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed = nullptr /* the bin-major copy rides along as extra workgroups */,
+                              const BiasUpdGroup* bias_upd = nullptr /* the bias half of a fused update as trailing workgroups */);
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 // the inverse transform on a T x T support with T = 5 or 9 (the offsets kl + k'l' of 3x3 / 5x5 kernels, weight_kernels.hip)
 hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias = nullptr /* fused: the DC-bin terms as extra workgroups */);
@@ -179,9 +187,10 @@ struct ChainArgs {
 };
 hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done = nullptr /* recorded by the dispatch itself */);
 // Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps
-struct PackSeg { const float* k; int n, lev, off; };              // taps [n][Nk*Nk] of one tensor, its pair, its element offset in a record
+struct PackSeg { const float* k; int n, lev, off; const float *g, *D; };   // taps [n][Nk*Nk] of one tensor, its pair, its element offset in a record; gradient / momentum of the same taps (TapUpd)
 struct PackArgs { PackSeg seg[16]; int nseg, L, E, Nk; int Nx[8], Ny[8]; int NxC, NyC; long Pc; float2* Wp; const float2* tw;
-                  unsigned char blk_seg[128]; int blk_start[128]; int nblk; /* (pack_blocks) element blocks: tensor, first element */ };
+                  unsigned char blk_seg[128]; int blk_start[128]; int nblk; /* (pack_blocks) element blocks: tensor, first element */
+                  int upd; float upd_del, upd_alpha, upd_gscale; /* upd != 0: taps read through the pending update (TapUpd) */ };
 void pack_blocks(PackArgs& g);
 hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st);
 

@@ -1,6 +1,7 @@
 // Device-side pieces of the operator form that more than one kernel file hosts (opform_kernels.hip, pruned_kernels.hip).
 #pragma once
 #include "internal.h"
+#include "update_device.h"
 
 namespace aefft {
 
@@ -73,6 +74,15 @@ __device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int
         float v[KK];                                               // every load of the copy in flight at once: one round trip
 #pragma unroll
         for (int w = 0; w < KK; ++w) v[w] = src[min(w * 256 + (int)threadIdx.x, nf - 1)];
+        if (g.upd) {                                               // (uniform) the taps as the pending update will leave them (TapUpd)
+            const float* gs = sd.g + (long)l0 * KK;
+            const float* ds = sd.D + (long)l0 * KK;
+            float gg[KK], dd[KK];
+#pragma unroll
+            for (int w = 0; w < KK; ++w) { const int f = min(w * 256 + (int)threadIdx.x, nf - 1); gg[w] = gs[f]; dd[w] = ds[f]; }
+#pragma unroll
+            for (int w = 0; w < KK; ++w) v[w] += -clip_step(gg[w] * g.upd_gscale, dd[w], g.upd_del, g.upd_alpha);
+        }
         float2 pv = make_float2(0.f, 0.f);                         // (the phase gathers ride in the same round trip)
         if (threadIdx.x < (RG + 1) * H) {
             const int k = threadIdx.x % H, r = threadIdx.x / H;

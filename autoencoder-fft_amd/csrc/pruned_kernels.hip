@@ -18,6 +18,7 @@
 #include "internal.h"
 #include "device_util.h"
 #include "opform_device.h"
+#include "update_device.h"
 #include <algorithm>
 
 namespace aefft {
@@ -38,7 +39,7 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
 template <int NK, int NL>
 __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float2* __restrict__ K,
                                                     const float2* __restrict__ tw, long planes, int Nx, int Ny,
-                                                    int rows_per_chunk, int ppb, int bx, int by, float2* lds)
+                                                    int rows_per_chunk, int ppb, int bx, int by, float2* lds, const TapUpd& upd = TapUpd{})
 {
     // The tap offsets are symmetric (kap = -H .. H, lam = -HL .. HL) and the phase of -kap is the conjugate of kap's, so a pair of
     // taps shares its phase:  c+ e + c- conj(e) = (c+ + c-) ex + i (c+ - c-) ey  (column factor, real taps: 2 FMAs per pair),
@@ -48,9 +49,30 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
     static_assert(NK % 2 == 1 && NL % 2 == 1, "symmetric tap offsets");
     const int Nyr = Ny / 2 + 1;
     float2* rowph = lds;                                 // [rows_per_chunk][H]: offsets 1 .. H
+    float* taps_s = reinterpret_cast<float*>(rowph + rows_per_chunk * H);      // [ppb][NK*NL]: the planes' taps, staged once per workgroup
     const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
     for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase(tw, i0 + t / H, t % H + 1, Nx, 1.f);
+    {
+        // (through the pending update when there is one -- uniform --: w - clip_step(g, D), TapUpd)
+        const long e0 = (long)bx * ppb * (NK * NL);
+        const long ne = min((long)ppb, planes - (long)bx * ppb) * (NK * NL);
+        for (int t0 = 0; t0 < ne; t0 += 3 * (int)blockDim.x) {          // (batches of independent loads: one round trip, not one per element)
+            float w[3], gq[3], dq[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const long t = min((long)t0 + u * blockDim.x + threadIdx.x, ne - 1);
+                w[u] = kern[e0 + t];
+                if (upd.g) { gq[u] = upd.g[e0 + t]; dq[u] = upd.D[e0 + t]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const long t = (long)t0 + u * blockDim.x + threadIdx.x;
+                if (upd.g) w[u] += -clip_step(gq[u] * upd.gscale, dq[u], upd.del, upd.alpha);
+                if (t < ne) taps_s[t] = w[u];
+            }
+        }
+    }
     __syncthreads();
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
     const long plane = (long)bx * ppb + pl;
@@ -60,7 +82,7 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
         float2 cp[HL > 0 ? HL : 1];
 #pragma unroll
         for (int l = 0; l < HL; ++l) cp[l] = phase(tw, j, l + 1, Ny, 1.f);
-        const float* c = kern + plane * NK * NL;
+        const float* c = taps_s + pl * (NK * NL);
         float2 v[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -100,9 +122,17 @@ __global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ ke
 
 // all pairs' kernel spectra in one launch: problem p owns workgroups [start[p], start[p+1]), plane groups fastest
 template <int NK, int NL>
-__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk)
+__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk, const BiasUpdGroup bu, const int nbias_start)
 {
     extern __shared__ float2 lds[];
+    if ((int)blockIdx.x >= nbias_start) {
+        // last of all: the bias half of a fused update (nothing in this launch reads b or p), one workgroup per pair
+        const BiasUpd& a = bu.a[blockIdx.x - nbias_start];
+        if (threadIdx.x == 0 && a.zero) *a.zero = 0.f;
+        for (int i = threadIdx.x; i < a.dM; i += blockDim.x) { const float Db = clip_step(a.db[i] * bu.gscale, a.Db[i], bu.del, bu.alpha); a.b[i] += -Db; a.Db[i] = Db; }
+        for (int i = threadIdx.x; i < a.dD; i += blockDim.x) { const float Dp = clip_step(a.dp[i] * bu.gscale, a.Dp[i], bu.del, bu.alpha); a.p[i] += -Dp; a.Dp[i] = Dp; }
+        return;
+    }
     if ((int)blockIdx.x >= g.start[g.n]) {
         // trailing workgroups: the bin-major copy of the spectra for the operator chain (opform_device.h), from the same taps
         if constexpr (NK == NL && (NK == 3 || NK == 5)) {
@@ -117,7 +147,7 @@ __global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, c
     const int lin = blockIdx.x - g.start[p];
     const PrunedProb& q = g.q[p];
     kspec_body<NK, NL>(static_cast<const float*>(q.src), static_cast<float2*>(q.dst), tw, q.planes, q.Nx, q.Ny, g.rows[p], g.ppb[p],
-                       lin % g.pblocks[p], lin / g.pblocks[p], lds);
+                       lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p]);
 }
 
 // Thread <-> (plane, column j) over a chunk of RB rows:
@@ -386,7 +416,7 @@ __global__ __launch_bounds__(256) void ksum_kernel(const float* __restrict__ par
     g[e] = s;
 }
 
-static size_t kspec_lds(int rows, int Nk) { return sizeof(float2) * (size_t)rows * Nk; }
+static size_t kspec_lds(int rows, int Nk, int ppb) { return sizeof(float2) * (size_t)rows * (Nk / 2) + sizeof(float) * (size_t)ppb * Nk * Nk; }   // row phases | the planes' taps
 // planes per workgroup (one thread per column) and rows per workgroup (>= 8, fewer when that would leave the
 // chip short of workgroups)
 static void kgrad_geom(long planes, int Nx, int Ny, int* RB, int* ppb, int* threads)
@@ -430,7 +460,7 @@ static hipError_t run_kspec(const float* k, float2* K, const float2* tw, long pl
     int chunks = 1;                                       // split the rows until the chip has ~1024 workgroups (>= 8 rows each)
     while (pblocks * chunks < 1024 && Nx / (chunks * 2) >= 8) chunks *= 2;
     const int rows = (Nx + chunks - 1) / chunks;
-    kspec_kernel<NK, NL><<<dim3((unsigned)pblocks, chunks), threads, kspec_lds(rows, NK), st>>>(k, K, tw, planes, Nx, Ny, rows, ppb);
+    kspec_kernel<NK, NL><<<dim3((unsigned)pblocks, chunks), threads, kspec_lds(rows, NK, ppb), st>>>(k, K, tw, planes, Nx, Ny, rows, ppb);
     return hipGetLastError();
 }
 
@@ -455,7 +485,8 @@ static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2
 }
 
 static PackArgs g_pack_none{};
-template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st, PackArgs* pk = nullptr)
+static BiasUpdGroup g_bu_none{};
+template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st, PackArgs* pk = nullptr, const BiasUpdGroup* bu = nullptr)
 {
     int total = 0; size_t lds = 0;
     for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); }
@@ -467,7 +498,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
         const int chunks = (q.Nx + 63) / 64;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
         g.start[p] = total; total += g.pblocks[p] * chunks;
-        lds = std::max(lds, kspec_lds(g.rows[p], NK));
+        lds = std::max(lds, kspec_lds(g.rows[p], NK, g.ppb[p]));
     }
     g.start[g.n] = total;
     int threads = 256;                                    // one thread per (plane in group, column)
@@ -475,7 +506,8 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     if (threads > 320) return hipErrorInvalidValue;
     int extra = 0;
     if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); }
-    kspec_group_kernel<NK, NL><<<dim3(total + extra), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none);
+    const int nb = bu ? bu->n : 0;
+    kspec_group_kernel<NK, NL><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
     return hipGetLastError();
 }
 
@@ -576,12 +608,12 @@ hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed)
+hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st, PackArgs* packed, const BiasUpdGroup* bias_upd)
 {
     if (!pruned_group_ok(g, tw, Nk, Nl)) return hipErrorInvalidValue;
-    if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st, packed);
-    if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st, packed);
-    return run_kspec_group<7, 7>(g, tw, st);
+    if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st, packed, bias_upd);
+    if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st, packed, bias_upd);
+    return run_kspec_group<7, 7>(g, tw, st, nullptr, bias_upd);
 }
 
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)

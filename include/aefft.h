@@ -70,7 +70,8 @@ enum {
     AEFFT_F_NOSPLITK = 1 << 14,   /* no split-K in the scalar contraction */
     AEFFT_F_POISON = 1 << 15,     /* NaN-fill every allocation (uninitialised reads show up in the tests) */
     AEFFT_F_NOOPFORM = 1 << 16,   /* training step per frame (batch contractions) instead of the operator form */
-    AEFFT_F_NOCHAIN = 1 << 17     /* operator form: the network on the basis frames layer by layer instead of one fused launch */
+    AEFFT_F_NOCHAIN = 1 << 17,    /* operator form: the network on the basis frames layer by layer instead of one fused launch */
+    AEFFT_F_NOFUSEUPD = 1 << 18   /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);

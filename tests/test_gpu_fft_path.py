@@ -200,7 +200,8 @@ def test_golden_forward_and_bursts(ctx, tag, D, N, maps, Nk, s):
 
 # Every alternative code path of the training step must give the oracle's numbers (development switches, aefft_ctx_set_flags).
 STEP_PATHS = ["", "NOOPFORM", "NOOPFORM,GTAPS", "NOOPFORM,NOQPATH", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOLAZY", "NOOPFORM,NOGROUP", "NOOPFORM,NOFUSEMSE",
-              "NOOPFORM,NOMFMA", "NOOPFORM,NOOVERLAP", "NOOPFORM,NOFUSECROP", "NOMFMA", "NOGROUP", "NOCHAIN", "NOCOMPACT", "NOLAZY", "NOOVERLAP"]
+              "NOOPFORM,NOMFMA", "NOOPFORM,NOOVERLAP", "NOOPFORM,NOFUSECROP", "NOMFMA", "NOGROUP", "NOCHAIN", "NOCOMPACT", "NOLAZY", "NOOVERLAP",
+              "NOFUSEUPD"]
 
 
 @pytest.mark.parametrize("path", STEP_PATHS)
@@ -275,7 +276,7 @@ def _step_vs_oracle(ctx, rng, B, D, Nx, Ny, maps, Nk, s):
     net.close()
 
 
-@pytest.mark.parametrize("path", ["", "NOCHAIN", "NOOPFORM", "NOOPFORM,NOGFWD", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOMFMA", "NOCOMPACT"])
+@pytest.mark.parametrize("path", ["", "NOCHAIN", "NOFUSEUPD", "NOOPFORM", "NOOPFORM,NOGFWD", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOMFMA", "NOCOMPACT"])
 def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, flags):
     """State carried from one training step to the next (the collapsed operator G of the innermost pair, cached spectra,
     stale-layer flags) must be invisible: step 2 on a live net == step 1 of a fresh net that starts from the live net's
