@@ -156,7 +156,9 @@ def variant_p1(aefft, torch, np, ctx, steps=4):
         net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
     ctx.sync(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    ctx.prof_enable(True); ctx.prof_reset()
+    ctx.prof_enable(True)
+    net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)     # (first launches of the profiled pass's own kernels: excluded)
+    ctx.sync(); ctx.prof_reset()
     net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
     prof = ctx.prof_read(); ctx.prof_enable(False)
     ok = bool(np.isfinite(mse.cpu().numpy()).all())
@@ -323,7 +325,10 @@ def main():
     if rank == 0 and not a.no_roofline:
         # per-kernel HIP events on the stream the kernels run on, over the same step
         # (side streams off: overlapped kernels would be charged each other's time)
-        ctx.prof_enable(True); ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(2):              # (the profiled pass launches kernels the overlapped pass does not -- e.g. the update as its own launch: first launches excluded)
+            net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
+        ctx.sync(); ctx.prof_reset()
         for _ in range(3):
             net.step_grad(frames, recon); net.step_apply(del0, 0, 0, 1.0 / world, mse)
         prof = ctx.prof_read(); ctx.prof_enable(False)
