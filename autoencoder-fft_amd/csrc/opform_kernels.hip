@@ -126,25 +126,34 @@ __global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
     const int by = blk % rgroups, bx = blk / rgroups;
     const long s = (long)bx * 64 + threadIdx.x;
     const int a = by * 4 + threadIdx.y;
-    if (s >= q.P || a >= dD) return;
-    const long u = map_up(s, q.Nx, q.Ny, g.Nx0, g.Ny0);
-    const int t = crop_dest32(s, q.Nx, q.Ny, q.NxO, q.NyO);                 // the bin of O^'s grid that lands on s, or -1
-    // every load of the thread is independent of every other: issue them all, then the arithmetic
-    float2 av[OPC], ov[OPC], Mh[OPC][OPC], ab[8][OPC];
+    const bool valid = s < q.P && a < dD;
+    const long sc = s < q.P ? s : q.P - 1;
+    const long u = map_up(sc, q.Nx, q.Ny, g.Nx0, g.Ny0);
+    const int t = crop_dest32(sc, q.Nx, q.Ny, q.NxO, q.NyO);                // the bin of O^'s grid that lands on s, or -1
+    // The four row threads of a bin need the same 16 moments and the same (up to) 8 x 4 elements of A: each loads a quarter of them
+    // into LDS (one round trip together with its own 8 loads) instead of all 48 -- the kernel is bound by its load instructions.
+    __shared__ float2 shv[48][64];                                          // [0,16): M^[j][k]; 16 + bb*4 + k: A[k][b0+bb]
+    const int b0 = bc * 8;
+    const int ac = a < dD ? a : dD - 1;
+    float2 av[OPC], ov[OPC], mine[12];
 #pragma unroll
     for (int j = 0; j < OPC; ++j) {
-        av[j] = q.A[((long)j * dD + a) * q.P + s];
-        ov[j] = q.O[((long)j * dD + a) * q.PO + (t >= 0 ? t : 0)];
-#pragma unroll
-        for (int k = 0; k < OPC; ++k) Mh[j][k] = g.Mhat[(long)(j * OPC + k) * g.P0 + u];
+        av[j] = q.A[((long)j * dD + ac) * q.P + sc];
+        ov[j] = q.O[((long)j * dD + ac) * q.PO + (t >= 0 ? t : 0)];
     }
-    const int b0 = bc * 8;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
-        if (b0 + bb < dD) {                                                   // uniform
-#pragma unroll
-            for (int k = 0; k < OPC; ++k) ab[bb][k] = q.A[((long)k * dD + b0 + bb) * q.P + s];
+    for (int i = 0; i < 12; ++i) {
+        const int e = threadIdx.y * 12 + i;
+        if (e < 16) mine[i] = g.Mhat[(long)e * g.P0 + u];
+        else {
+            const int bb = (e - 16) >> 2, k = (e - 16) & 3;
+            mine[i] = q.A[((long)k * dD + min(b0 + bb, dD - 1)) * q.P + sc];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) shv[threadIdx.y * 12 + i][threadIdx.x] = mine[i];
+    __syncthreads();
+    if (!valid) return;
     float2 U[OPC];
 #pragma unroll
     for (int k = 0; k < OPC; ++k) U[k] = make_float2(0.f, 0.f);
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
     for (int j = 0; j < OPC; ++j) {
         const float2 E = t >= 0 ? make_float2(ov[j].x - av[j].x, ov[j].y - av[j].y) : make_float2(-av[j].x, -av[j].y);
 #pragma unroll
-        for (int k = 0; k < OPC; ++k) cfma2(U[k], E, Mh[j][k]);
+        for (int k = 0; k < OPC; ++k) cfma2(U[k], E, shv[j * OPC + k][threadIdx.x]);
     }
     if (s == 0 && bc == 0) { q.es[2 * a] = U[OPC - 1].x; q.es[2 * a + 1] = U[OPC - 1].y; }
 #pragma unroll
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
         if (b0 + bb >= dD) break;
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], ab[bb][k]);
+        for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], shv[16 + bb * 4 + k][threadIdx.x]);
         q.S[((long)a * dD + b0 + bb) * q.P + s] = acc;
     }
 }
