@@ -270,6 +270,15 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
     const long s = blk * BT + bl;
     const bool ok = s < q.P;
     const long sc = ok ? s : q.P - 1;
+    // the 4x4 moments of the tile's bins, once per workgroup (every row thread needs them in phase 2: 16 loads each otherwise);
+    // issued here, in the same round trip as the A tile
+    float2* Ms = Ts + (size_t)dM * OPC * BT + 8 + 256 * OPC;           // [OPC*OPC][BT], behind Rs
+    float2 mval = make_float2(0.f, 0.f);
+    if ((int)threadIdx.x < OPC * OPC * BT) {
+        const int e = threadIdx.x / BT, b2 = threadIdx.x - e * BT;
+        const long s2 = min(blk * BT + b2, q.P - 1);
+        mval = g.Mhat[(long)e * g.P0 + map_up(s2, q.Nx, q.Ny, g.Nx0, g.Ny0)];
+    }
     for (int i0 = 0; i0 < OPC * dD * BT; i0 += 256 * 4) {
         float2 v[4];
 #pragma unroll
@@ -282,6 +291,7 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const int idx = i0 + w * 256 + threadIdx.x; if (idx < OPC * dD * BT) As[idx] = v[w]; }
     }
+    if ((int)threadIdx.x < OPC * OPC * BT) Ms[threadIdx.x] = mval;
     __syncthreads();
     const float NN = (float)q.Nx * (float)q.Ny;
     const float idM = 1.0f / (float)dM, idD = 1.0f / (float)dD;
@@ -317,12 +327,6 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
     __syncthreads();
     float part = 0.f;
     {
-        const long u = map_up(sc, q.Nx, q.Ny, g.Nx0, g.Ny0);
-        float2 Mh[OPC][OPC];
-#pragma unroll
-        for (int i = 0; i < OPC; ++i)
-#pragma unroll
-            for (int j = 0; j < OPC; ++j) Mh[i][j] = g.Mhat[(long)(i * OPC + j) * g.P0 + u];
         // rows a over the row threads; when there are more row threads than rows, KS of them share a row and split the sum over m
         int KS = 1;
         while (KS < 8 && dD * KS * 2 <= RT) KS *= 2;
@@ -379,7 +383,7 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
             for (int k = 0; k < OPC; ++k) {
                 float2 v = make_float2(0.f, 0.f);
 #pragma unroll
-                for (int k2 = 0; k2 < OPC; ++k2) cfmac(v, Mh[k][k2], r[k2]);
+                for (int k2 = 0; k2 < OPC; ++k2) cfmac(v, Ms[(k * OPC + k2) * BT + bl], r[k2]);
                 part += r[k].x * v.x - r[k].y * v.y;
             }
         }
@@ -578,7 +582,7 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
         // bins per workgroup: whole 128-byte lines when the pair still yields >= 128 workgroups and its tiles fit 64 KB of LDS
         int bt = 16;
         while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
-        size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2);
+        size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2) + (size_t)OPC * OPC * bt * sizeof(float2);
         const bool pk = i == g.n - 1 && g.Wp && q.dD <= CH_VMAX && q.dM <= CH_VMAX;
         if (!pk && q.dM == 8 && q.dD <= 4 && !flag(AEFFT_F_NOFAST)) { bt = 32; need = (size_t)OPC * (4 + 8) * 32 * sizeof(float2) + 64; }     // opmse_small_body (bt == 32 selects it)
         if (i == g.n - 1 && !pk) g.Wp = nullptr;
