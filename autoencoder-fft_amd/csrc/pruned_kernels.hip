@@ -281,12 +281,14 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < CR * H) rowph[t] = v[u]; }
     }
-    for (int t0 = 0; t0 < Nyr * NL; t0 += NT * 5) {
-        float2 v[5];
+    // (column phases of the offsets 0 .. HLc only, stored at [j][HLc + lam]: the column stage reads nothing else)
+    constexpr int HLc = NL / 2, NLc = HLc + 1;
+    for (int t0 = 0; t0 < Nyr * NLc; t0 += NT * 3) {
+        float2 v[3];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, Nyr * NL - 1); v[u] = phase(tw, t / NL, t % NL - NL / 2, Ny, -1.f); }
+        for (int u = 0; u < 3; ++u) { const int t = min(t0 + u * NT + (int)threadIdx.x, Nyr * NLc - 1); v[u] = phase(tw, t / NLc, t % NLc, Ny, -1.f); }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < Nyr * NL) colph[t] = v[u]; }
+        for (int u = 0; u < 3; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < Nyr * NLc) colph[(t / NLc) * NL + HLc + t % NLc] = v[u]; }
     }
     __syncthreads();
     // t_k = sum_i d_i e^{+i th_k(i)} for the offsets kap = k - H.  The offsets come in conjugate pairs: d*p and d*conj(p) share their
