@@ -39,6 +39,25 @@ def test_conv_gpu_semantics(ctx, dD, dM, N, Nk, B):
         assert np.abs(got[i] - ref).max() < 1e-5 * max(1, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dD,dM,N,Nk,B,sem", [(50, 3, 64, 3, 2, "gpu"), (6, 1, 128, 5, 1, "gpu"), (9, 2, 96, 3, 1, "cpu"), (5, 4, 72, 5, 2, "gpu"),
+                                              (20, 3, 80, 7, 1, "cpu")])
+def test_conv_few_maps_register_blocked_kernel(ctx, flags, dD, dM, N, Nk, B, sem):
+    """dconv4_kernel (<= 4 output maps, planes >= 64 wide): against the oracle and against the tile kernel (NOFAST), channel
+    counts that are not a multiple of the 4 it prefetches, widths that are not a multiple of its 64-column tile, both semantics."""
+    x, c, b, f, p = _case(np.random.default_rng(dD * 3 + dM + N), dD, dM, N, Nk, B)
+    flags()
+    got = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b), semantics=sem))
+    flags("NOFAST")
+    old = host(ctx.conv_spatial(ctx.dev(x), ctx.dev(c), ctx.dev(b), semantics=sem))
+    flags()
+    scale = max(1.0, np.abs(old).max())
+    assert np.abs(got - old).max() < 2e-5 * scale
+    if sem == "gpu":
+        for i in range(B):
+            ref = S.conv(x[i], c, b)
+            assert np.abs(got[i] - ref).max() < 1e-5 * max(1, np.abs(ref).max())
+
+
 def test_conv_cpu_semantics_matches_compiled_reference(ctx):
     """cpu_semantics=1 reproduces netlib.cpp Conv; checked against the compiled reference when present."""
     L = cpu.reference() or cpu.port()
