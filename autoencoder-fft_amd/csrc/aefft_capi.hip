@@ -1270,7 +1270,11 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     n->op_state = op;
     RET_IF(join_recon(ctx));
     n->xx_done = false; n->ox_done = 0;
-    for (auto& q : n->pr) RET_IF(ensure_spectra(n, q));
+    // (the fused chain launch reads the innermost pair from the bin-major record Wp only: its planar spectra, which a training step
+    // in operator form does not refresh, are formed when something else asks for them)
+    const bool chain_plan = op && lazy && n->Wp && (n->compact || L == 1) &&
+        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP));
+    for (int l = 0; l < L; ++l) if (!(chain_plan && l == L - 1 && L > 1)) RET_IF(ensure_spectra(n, n->pr[l]));
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
     const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !flag(AEFFT_F_NOPREFETCH);
     if (prefetch) {
@@ -1292,8 +1296,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     n->pr[0].X = op ? n->A0hat : n->Xf;
     // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
     // hidden layers not materialised, decoder outputs on the coarsest grid's support
-    const bool chain_ok = op && lazy && n->Wp && (n->compact || L == 1) &&
-        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP));
+    const bool chain_ok = chain_plan;
     const double mom_bytes = ((double)BF * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0;
     if (op && !chain_ok) {
         Bracket br(ctx, KID_OPFORM, mom_bytes);
@@ -1708,6 +1711,13 @@ static int grads_grouped(aefft_net* n)
             const float Norm = grad_norm(q.dM, q.dD, q.Nx, q.Ny);
             bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, qpath ? nullptr : q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
                                    (float)q.Nx * (float)q.Ny, Norm, q.O_stale ? n->Pc : q.P, qpath ? q.es : nullptr, op ? q.es : nullptr};
+            if (!q.spectra_valid) {
+                // (operator form, innermost pair: the step left its planar spectra stale; F at the DC bin is record 0 of the
+                // bin-major copy -- element (d1*dM + m) of the F segment, stride 1.  Only F is read through P in this form.)
+                if (!(op && qpath && l == n->L - 1 && n->Wp && n->packed_valid)) return fail(ctx, AEFFT_ESTATE, "gradient: stale kernel spectra");
+                bg.a[l].F = n->Wp + n->pack.seg[n->L].off;
+                bg.a[l].P = 1;
+            }
             bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
             if (qpath) {
                 // weight gradients through Q = pruned inverse transform of S on the (2Nk-1)^2 offsets (weight_kernels.hip): no dc|df spectra
@@ -1860,12 +1870,24 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             hipError_t e = launch_update_group(ug, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
         }
+        // Operator form: nothing in a training step reads the innermost pair's PLANAR spectra (the chain, the post-update MSE and
+        // the DC-bin gradient terms take that pair from the bin-major record): they are left stale (a fifth of the bytes of this
+        // launch) and formed on demand (ensure_spectra) by whatever else asks for them.
+        const bool skip_inner = ride && n->L > 1 && n->pr[n->L - 1].P == n->pack.Pc && n->pr[n->L - 1].dD <= CH_VMAX && n->pr[n->L - 1].dM <= CH_VMAX &&
+                                !flag(AEFFT_F_NOCHAIN) && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
+        if (skip_inner) {
+            const Pair& qi = n->pr[n->L - 1];
+            pg.n = n->L - 1;
+            kbytes -= 2.0 * qi.dM * qi.dD * (qi.P * 8.0 + qi.Nk * qi.Nl * 4.0);
+        }
         hipError_t e;
         {
             Bracket br(ctx, KID_KSPEC, kbytes + ((n->op_state && n->Wp) ? (double)n->pack.Pc * n->pack.E * 8.0 : 0.0));
             e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr, fused_upd ? &bu : nullptr);
             if (e == hipSuccess && ride) n->packed_valid = true;
+            if (e == hipSuccess && skip_inner) n->pr[n->L - 1].spectra_valid = false;
         }
+        pg.n = n->L;
         n->pack.upd = 0;
         if (e != hipSuccess) {
             if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kspec(group)", e);

@@ -217,7 +217,7 @@ hipError_t launch_recon_expand(const float2* O0, const float2* Xf, float2* Of, i
     return launch_op_expand(O0, Xf, Of, B, D0, D0, Nx0, Ny0, NxO, NyO, st);
 }
 
-constexpr int CH_VMAX = 128, CH_WL = 6144;
+constexpr int CH_WL = 6144;       // (CH_VMAX: internal.h)
 
 // out[r][c] = scale * sum_k W[r][k] V[k][c] (+ bias[r] NN on the affine column at the DC bin); W = a row-major matrix of the
 // item's packed record, read straight from global memory (contiguous rows, L2-resident), V in LDS.  Thread = one output.
