@@ -1297,12 +1297,6 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
     // hidden layers not materialised, decoder outputs on the coarsest grid's support
     const bool chain_ok = chain_plan;
-    const double mom_bytes = ((double)BF * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0;
-    if (op && !chain_ok) {
-        Bracket br(ctx, KID_OPFORM, mom_bytes);
-        hipError_t e = launch_moment(n->Xf, n->Mhat, BF, n->D, n->pr[0].P, ctx->cur);
-        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "moment", e);
-    }
     bool chained = false, fork_recorded = false;
     if (chain_ok) {
         ChainArgs ca{};
@@ -1316,8 +1310,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         }
         RET_IF(ensure_packed(n));
         ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
-        ca.mom_Xf = n->Xf; ca.mom_M = n->Mhat; ca.mom_B = BF;            // the batch moments share the launch
-        Bracket br(ctx, KID_CHAIN, bytes + mom_bytes);
+        Bracket br(ctx, KID_CHAIN, bytes);
         // the reconstruction's side stream forks right behind this launch (below): its completion signal is the fork event
         const bool fork_here = recon_d && lazy && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && !ctx->prof &&
                                !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
@@ -1650,18 +1643,18 @@ static int grads_grouped(aefft_net* n)
     Contract qs[8];
     const bool op = n->op_state;
     if (op) {
-        // S_l = sum_b (O_b - X_b) X_b^H and the DC error sums of every pair from the operators and the batch moments: one launch
+        // the batch moments, S_l = sum_b (O_b - X_b) X_b^H and the DC error sums of every pair from the operators: one launch
         SgradGroup sg{};
-        double bytes = 0;
+        double bytes = ((double)n->B * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0;      // the input spectra in, the moments out
         for (int l = 0; l < n->L; ++l) {
             Pair& q = n->pr[l];
             const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
             sg.q[l] = OpPair{q.X, q.O_stale ? q.Oc : q.O, q.S, q.es, q.dD, q.Nx, q.Ny, nxo, nyo, q.P, bins(nxo, nyo)};
-            bytes += ((double)OPC * q.dD * (q.P + bins(nxo, nyo)) + (double)OPC * OPC * q.P + (double)q.dD * q.dD * q.P) * 8.0;
+            bytes += ((double)OPC * q.dD * (q.P + bins(nxo, nyo)) + (double)q.dD * q.dD * q.P) * 8.0;
         }
-        sg.n = n->L; sg.Mhat = n->Mhat; sg.Nx0 = n->pr[0].Nx; sg.Ny0 = n->pr[0].Ny; sg.P0 = n->pr[0].P;
+        sg.n = n->L; sg.Xf = n->Xf; sg.Mout = n->Mhat; sg.B = n->B; sg.D0 = n->D; sg.Nx0 = n->pr[0].Nx; sg.Ny0 = n->pr[0].Ny; sg.P0 = n->pr[0].P;
         Bracket br(ctx, KID_SGRAD, bytes);
-        hipError_t e = launch_sgrad_group(sg, ctx->cur);
+        hipError_t e = launch_msgrad_group(sg, ctx->cur);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "sgrad", e);
     }
     bool comp = false;

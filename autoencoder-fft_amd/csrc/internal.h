@@ -152,7 +152,6 @@ const float2* twiddle_table();   // device address of the table uploaded by uplo
 // and the reconstruction.  Same sums as gradient_k_io / mse_fft (fft_backproplib.cu:395-498), batch contracted first.
 constexpr int OPC = 4;
 hipError_t launch_basis_fill(float2* A0 /*[OPC][D0][P0]*/, int D0, long P0, hipStream_t st);
-hipError_t launch_moment(const float2* Xf /*[B][D0][P0]*/, float2* Mhat /*[OPC][OPC][P0]*/, int B, int D0, long P0, hipStream_t st);
 struct OpPair {
     const float2* A;        // A_l    [OPC][dD][P]      (the pair's input on the basis frames)
     const float2* O;        // O^_l   [OPC][dD][PO]     (its decoder output on the basis frames, stored on the grid [NxO][NyO/2+1])
@@ -160,8 +159,10 @@ struct OpPair {
     float* es;              // out:   [2*dD]            es[d] = sum_b (O_b - X_b)[d](0,0)
     int dD, Nx, Ny, NxO, NyO; long P, PO;
 };
-struct SgradGroup { OpPair q[8]; int n; int start[9]; const float2* Mhat; int Nx0, Ny0; long P0; };
-hipError_t launch_sgrad_group(SgradGroup& g, hipStream_t st);
+// (msgrad_kernel: the batch moments are formed from the input spectra Xf [B][D0][P0] inside the launch and stored to Mout [OPC*OPC][P0] in their
+// CENTRED form -- layout in opform_kernels.hip)
+struct SgradGroup { OpPair q[8]; int n; int start[9], bt[8]; const float2* Xf; float2* Mout; int B, D0, Nx0, Ny0; long P0; };
+hipError_t launch_msgrad_group(SgradGroup& g, hipStream_t st);
 // O_0,b = O^_0 [x_b; 1] on the grid O^_0 is stored on: Of [B][D0][PO]
 hipError_t launch_recon_expand(const float2* O0, const float2* Xf, float2* Of, int B, int D0, int Nx0, int Ny0, int NxO, int NyO, hipStream_t st);
 // X_l,b = A_l [x_b; 1] for get_layer-style exports: out [B][dD][P] on the grid [Nx][Ny/2+1] of A
@@ -184,7 +185,6 @@ struct ChainArgs {
     const float2* Wp; int E;   // bin-major copy of every matrix a coarsest-grid bin needs (kspec_packed_kernel)
     int tile_start[9];         // (filled by launch_chain) first workgroup of the planar tiles of grid j
     int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
-    const float2* mom_Xf; float2* mom_M; int mom_B;   // nullable: the batch moments M^ ride along as trailing workgroups (moment_body)
 };
 hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done = nullptr /* recorded by the dispatch itself */);
 // Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps

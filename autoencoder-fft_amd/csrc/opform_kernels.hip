@@ -25,6 +25,27 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 __device__ __forceinline__ void cfma2(float2& acc, float2 a, float2 b) { acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x); acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y); }
 __device__ __forceinline__ void cfmac(float2& acc, float2 a, float2 b) { acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(a.y, b.y, acc.x); acc.y = fmaf(a.y, b.x, acc.y); acc.y = fmaf(-a.x, b.y, acc.y); }   // += a * conj(b)
+// element `e` of a base with a 32-bit BYTE offset: with a uniform base the load takes the scalar-base + 32-bit lane offset form (callers
+// guarantee e * 8 < 2^32)
+__device__ __forceinline__ float2 ld8(const float2* base, unsigned e) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + e * 8u); }
+
+// r M^ r^H for one row r of an operator, with M^ in its stored CENTRED form (msgrad_kernel): r~_3 = r_3 + sum_j r_j xbar_j, then
+// sum_{j,k<3} r_j M[j][k] conj(r_k) + B |r~_3|^2.  Mget(e): entry e = j*OPC + k of M^ at the row's bin.
+template <typename MG> __device__ __forceinline__ float quad_centred(const float2 (&r)[OPC], MG Mget)
+{
+    float2 r3 = r[OPC - 1];
+#pragma unroll
+    for (int j = 0; j < OPC - 1; ++j) cfma2(r3, r[j], Mget(j * OPC + OPC - 1));
+    float part = Mget(OPC * OPC - 1).x * (r3.x * r3.x + r3.y * r3.y);
+#pragma unroll
+    for (int k = 0; k < OPC - 1; ++k) {
+        float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k2 = 0; k2 < OPC - 1; ++k2) cfmac(v, Mget(k * OPC + k2), r[k2]);      // M[k][k2] conj(r_k2)
+        part += r[k].x * v.x - r[k].y * v.y;
+    }
+    return part;
+}
 
 // ------------------------------------------------------------------------------------------
 // basis frames: A_0[j][d][u] = 1 if j == d < D0 else 0 (column OPC-1 = the zero input)
@@ -46,144 +67,204 @@ hipError_t launch_basis_fill(float2* A0, int D0, long P0, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------
-// second moments of the batch: M^[i][j][u] = sum_b x^_b[i][u] conj(x^_b[j][u]),  x^ = [x_0 .. x_{D0-1}, 0.., 1]
-// Workgroup = 64 bins x 4 frame slices; the slices are summed in slice order (deterministic).
+// Batch moments and S_l, es_l of every pair in ONE launch (msgrad_kernel).
+//
+// CENTRED moments.  With xbar[u] = mean_b x_b[u] and dl_b = x_b - xbar the affine form X_l,b = A [x_b; 1] reads
+// A_x dl_b + (A_x xbar + A_1): the operators keep their linear columns and the affine column becomes the response to the MEAN
+// frame, A~_1 = A_1 + sum_j A_j xbar_j.  In that basis the batch moment matrix is block diagonal, [sum_b dl dl^H, 0; 0, B], and
+//       S   = sum_b (O_b - X_b) X_b^H = E_x (sum dl dl^H) A_x^H + B E~_1 A~_1^H,          E = O^ - A
+//       mse = sum_b |R [x_b; 1]|^2    = R_x (sum dl dl^H) R_x^H + B |R~_1|^2
+// are sums of terms that are each as small as the per-frame quantities themselves.  The uncentred form M^ = sum [x;1][x;1]^H
+// cancels catastrophically wherever the frames share a mean that R (a trained net) or E maps to almost zero -- the DC bin of
+// any video, and every bin of the smooth component the synthetic frames share.
+// M^ as stored ([OPC*OPC][P0], consumed by the MSE kernels): (j,k<3) sum_b dl_j conj(dl_k); (j,3) xbar_j; (3,j) conj(xbar_j); (3,3) B.
+// The sums use frame 0 as a provisional mean (one pass: sum (x-K), sum (x-K)(x-K)^H, then the exact shift to the true mean).
+//
+// Workgroup = BT consecutive bins of one pair's grid.  Phase A: threads (bin, frame slice) accumulate the moments of the tile's
+// bins from the input spectra (every pair's workgroups form the moments of their own bins: no workgroup waits for another; the
+// workgroups of pair 0, whose grid is the moments' grid, also store them).  Phase B: threads (bin, row a): U[a][.] = E~ M,
+// S[a][b] = sum_k U[a][k] conj(A~[b][k]) for every b.  All global loads of a workgroup are issued up front (one round trip).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void moment_body(const float2* __restrict__ Xf, float2* __restrict__ M, int B, int D0, long P0, long blk, int tx, int sl)
+__global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
 {
-    __shared__ float2 red[3][9][64];
-    const long u = blk * 64 + tx;
-    const long uc = u < P0 ? u : P0 - 1;
-    // upper triangle without the constant (3,3): (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3)
-    float2 acc[9];
+    extern __shared__ float2 sh[];
+    const int tid = threadIdx.x;
+    int p = g.n - 1;                                                // pair n-1 owns the first workgroups (most dependent steps per workgroup), pair 0 the last
 #pragma unroll
-    for (int e = 0; e < 9; ++e) acc[e] = make_float2(0.f, 0.f);
-    const int nb = (B + 3) / 4;                                       // frames per slice
-    const int b0 = sl * nb, b1 = min(B, b0 + nb);
-    for (int b = b0; b < b1; b += 4) {
-        float2 x[4][3];
+    for (int i = 6; i >= 0; --i) if (i < g.n - 1 && (int)blockIdx.x >= g.start[i]) p = i;
+    const OpPair q = g.q[p];                                        // (by value: one bulk scalar load, not one per field use)
+    const int BT = g.bt[p], RT = 256 / BT;                          // bins per workgroup; row threads == frame slices
+    const int dD = q.dD, D0 = g.D0, B = g.B;
+    const long s0 = (long)(blockIdx.x - g.start[p]) * BT;
+    const int bl = tid % BT, ry = tid / BT;
+    const long s = s0 + bl;
+    const bool ok = s < q.P;
+    const long sc = ok ? s : q.P - 1;
+    const unsigned u = (unsigned)map_up(sc, q.Nx, q.Ny, g.Nx0, g.Ny0);
+    const unsigned P0 = (unsigned)g.P0;
+    const int nA = OPC * dD * BT;
+    float2* red = sh;                                               // [RT][9][BT]     per-slice partial moments; dead after the slice sums, then:
+    float2* As = sh;                                                // [OPC][dD][BT]   A  (affine column centred in place)
+    float2* Os = As + nA;                                           // [OPC][dD][BT]   O^ on the support, 0 elsewhere
+    float2* mom = sh + max(9 * 256, 2 * nA);                        // [9][BT]         slice sums: s_0..2, m_00 m_01 m_02 m_11 m_12 m_22
+    float2* Kl = mom + 9 * BT;                                      // [3][BT]         provisional mean (frame 0)
+    float2* Ms = Kl + 3 * BT;                                       // [16][BT]        M^ of the tile's bins (layout above)
+    // ---- every global load of the workgroup: the A and O^ tiles, then this thread's frames ----
+    float2 va[4], vo[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+    for (int w = 0; w < 4; ++w) {
+        const int idx = min(w * 256 + tid, nA - 1);
+        const int kd = idx / BT, b2 = idx - kd * BT;
+        const long s2 = min(s0 + b2, q.P - 1);
+        const int t2 = crop_dest32(s2, q.Nx, q.Ny, q.NxO, q.NyO);
+        va[w] = q.A[(long)kd * q.P + s2];
+        vo[w] = q.O[(long)kd * q.PO + (t2 >= 0 ? t2 : 0)];
+        if (t2 < 0) vo[w] = make_float2(0.f, 0.f);
+    }
+    float2 K[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) K[d] = d < D0 ? ld8(g.Xf + (size_t)d * P0, u) : make_float2(0.f, 0.f);
+    float2 sx[3], mm[6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sx[d] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) mm[e] = make_float2(0.f, 0.f);
+    constexpr int FC = 8;                                           // frames per batch of loads
+    for (int b0 = ry; b0 < B; b0 += RT * FC) {
+        float2 x[FC][3];
+#pragma unroll
+        for (int f = 0; f < FC; ++f)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int bb = min(b + f, b1 - 1);
-                x[f][d] = d < D0 ? ld_stream(&Xf[((long)bb * D0 + d) * P0 + uc]) : make_float2(0.f, 0.f);     // (the last full pass over the input spectra)
+                const int bb = min(b0 + f * RT, B - 1);
+                x[f][d] = d < D0 ? ld8(g.Xf + ((size_t)bb * D0 + d) * P0, u) : make_float2(0.f, 0.f);
             }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            if (b + f >= b1) break;
-            const float2 x0 = x[f][0], x1 = x[f][1], x2 = x[f][2];
-            cfmac(acc[0], x0, x0); cfmac(acc[1], x0, x1); cfmac(acc[2], x0, x2); acc[3].x += x0.x; acc[3].y += x0.y;
-            cfmac(acc[4], x1, x1); cfmac(acc[5], x1, x2); acc[6].x += x1.x; acc[6].y += x1.y;
-            cfmac(acc[7], x2, x2); acc[8].x += x2.x; acc[8].y += x2.y;
-        }
-    }
-    if (sl > 0) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) red[sl - 1][e][tx] = acc[e];
-    }
-    __syncthreads();
-    if (sl > 0 || u >= P0) return;
-#pragma unroll
-    for (int s2 = 0; s2 < 3; ++s2)
-#pragma unroll
-        for (int e = 0; e < 9; ++e) { const float2 v = red[s2][e][tx]; acc[e].x += v.x; acc[e].y += v.y; }
-    const int ei[9] = {0, 0, 0, 0, 1, 1, 1, 2, 2}, ej[9] = {0, 1, 2, 3, 1, 2, 3, 2, 3};
-#pragma unroll
-    for (int e = 0; e < 9; ++e) {
-        float2 v = acc[e];
-        if (ei[e] == ej[e]) v.y = 0.f;
-        M[(long)(ei[e] * OPC + ej[e]) * P0 + u] = v;
-        if (ei[e] != ej[e]) M[(long)(ej[e] * OPC + ei[e]) * P0 + u] = make_float2(v.x, -v.y);
-    }
-    M[(long)(3 * OPC + 3) * P0 + u] = make_float2((float)B, 0.f);
-}
-__global__ __launch_bounds__(256) void moment_kernel(const float2* __restrict__ Xf, float2* __restrict__ M, int B, int D0, long P0)
-{
-    moment_body(Xf, M, B, D0, P0, blockIdx.x, threadIdx.x, threadIdx.y);
-}
-hipError_t launch_moment(const float2* Xf, float2* Mhat, int B, int D0, long P0, hipStream_t st)
-{
-    if (B < 1 || D0 < 1 || D0 > OPC - 1 || P0 < 1) return hipErrorInvalidValue;
-    moment_kernel<<<dim3((unsigned)((P0 + 63) / 64)), dim3(64, 4), 0, st>>>(Xf, Mhat, B, D0, P0);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// S_l and es_l of every pair in one launch.  Thread = (bin s of pair l's grid, row a): E[a][.] = O^[.][a][t] - A[.][a][s],
-// U[a][.] = E M^[u], then S[a][b] = sum_k U[a][k] conj(A[k][b][s]) for every b.  Lanes run along the bins (coalesced planes).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sgrad_kernel(const SgradGroup g)
-{
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
-    const OpPair q = g.q[p];                                        // (by value: one bulk scalar load, not one per field use)
-    const int dD = q.dD;
-    const int rgroups = (dD + 3) / 4, bchunks = (dD + 7) / 8;
-    int blk = blockIdx.x - g.start[p];
-    const int bc = blk % bchunks; blk /= bchunks;
-    const int by = blk % rgroups, bx = blk / rgroups;
-    const long s = (long)bx * 64 + threadIdx.x;
-    const int a = by * 4 + threadIdx.y;
-    const bool valid = s < q.P && a < dD;
-    const long sc = s < q.P ? s : q.P - 1;
-    const long u = map_up(sc, q.Nx, q.Ny, g.Nx0, g.Ny0);
-    const int t = crop_dest32(sc, q.Nx, q.Ny, q.NxO, q.NyO);                // the bin of O^'s grid that lands on s, or -1
-    // The four row threads of a bin need the same 16 moments and the same (up to) 8 x 4 elements of A: each loads a quarter of them
-    // into LDS (one round trip together with its own 8 loads) instead of all 48 -- the kernel is bound by its load instructions.
-    __shared__ float2 shv[48][64];                                          // [0,16): M^[j][k]; 16 + bb*4 + k: A[k][b0+bb]
-    const int b0 = bc * 8;
-    const int ac = a < dD ? a : dD - 1;
-    float2 av[OPC], ov[OPC], mine[12];
-#pragma unroll
-    for (int j = 0; j < OPC; ++j) {
-        av[j] = q.A[((long)j * dD + ac) * q.P + sc];
-        ov[j] = q.O[((long)j * dD + ac) * q.PO + (t >= 0 ? t : 0)];
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int e = threadIdx.y * 12 + i;
-        if (e < 16) mine[i] = g.Mhat[(long)e * g.P0 + u];
-        else {
-            const int bb = (e - 16) >> 2, k = (e - 16) & 3;
-            mine[i] = q.A[((long)k * dD + min(b0 + bb, dD - 1)) * q.P + sc];
+        for (int f = 0; f < FC; ++f) {
+            if (b0 + f * RT >= B) break;
+            const float2 y0 = make_float2(x[f][0].x - K[0].x, x[f][0].y - K[0].y), y1 = make_float2(x[f][1].x - K[1].x, x[f][1].y - K[1].y),
+                         y2 = make_float2(x[f][2].x - K[2].x, x[f][2].y - K[2].y);
+            sx[0].x += y0.x; sx[0].y += y0.y; sx[1].x += y1.x; sx[1].y += y1.y; sx[2].x += y2.x; sx[2].y += y2.y;
+            cfmac(mm[0], y0, y0); cfmac(mm[1], y0, y1); cfmac(mm[2], y0, y2); cfmac(mm[3], y1, y1); cfmac(mm[4], y1, y2); cfmac(mm[5], y2, y2);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) shv[threadIdx.y * 12 + i][threadIdx.x] = mine[i];
-    __syncthreads();
-    if (!valid) return;
-    float2 U[OPC];
+    for (int d = 0; d < 3; ++d) red[(ry * 9 + d) * BT + bl] = sx[d];
 #pragma unroll
-    for (int k = 0; k < OPC; ++k) U[k] = make_float2(0.f, 0.f);
+    for (int e = 0; e < 6; ++e) red[(ry * 9 + 3 + e) * BT + bl] = mm[e];
+    if (ry == 0) {
 #pragma unroll
-    for (int j = 0; j < OPC; ++j) {
-        const float2 E = t >= 0 ? make_float2(ov[j].x - av[j].x, ov[j].y - av[j].y) : make_float2(-av[j].x, -av[j].y);
-#pragma unroll
-        for (int k = 0; k < OPC; ++k) cfma2(U[k], E, shv[j * OPC + k][threadIdx.x]);
+        for (int d = 0; d < 3; ++d) Kl[d * BT + bl] = K[d];
     }
-    if (s == 0 && bc == 0) { q.es[2 * a] = U[OPC - 1].x; q.es[2 * a + 1] = U[OPC - 1].y; }
+    __syncthreads();
+    for (int i = tid; i < 9 * BT; i += 256) {                       // slices -> one sum, in slice order (deterministic)
+        const int e = i / BT, b2 = i - e * BT;
+        float2 a = red[e * BT + b2];
+#pragma unroll 4
+        for (int r2 = 1; r2 < RT; ++r2) { const float2 v = red[(r2 * 9 + e) * BT + b2]; a.x += v.x; a.y += v.y; }
+        mom[i] = a;
+    }
+    __syncthreads();
+    // the tiles take the place of the per-slice partial sums (held in registers since the first round trip)
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-        if (b0 + bb >= dD) break;
-        float2 acc = make_float2(0.f, 0.f);
+    for (int w = 0; w < 4; ++w) { const int idx = w * 256 + tid; if (idx < nA) { As[idx] = va[w]; Os[idx] = vo[w]; } }
+    for (int i0 = 1024; i0 < nA; i0 += 1024) {                      // tiles larger than 4 elements per thread (dD > 32): further round trips
+        float2 wa[4], wo[4];
 #pragma unroll
-        for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], shv[16 + bb * 4 + k][threadIdx.x]);
-        q.S[((long)a * dD + b0 + bb) * q.P + s] = acc;
+        for (int w = 0; w < 4; ++w) {
+            const int idx = min(i0 + w * 256 + tid, nA - 1);
+            const int kd = idx / BT, b2 = idx - kd * BT;
+            const long s2 = min(s0 + b2, q.P - 1);
+            const int t2 = crop_dest32(s2, q.Nx, q.Ny, q.NxO, q.NyO);
+            wa[w] = q.A[(long)kd * q.P + s2];
+            wo[w] = t2 >= 0 ? q.O[(long)kd * q.PO + t2] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int idx = i0 + w * 256 + tid; if (idx < nA) { As[idx] = wa[w]; Os[idx] = wo[w]; } }
+    }
+    const float fB = (float)B, iB = 1.0f / (float)B;
+    const bool store_m = g.Mout != nullptr && p == 0;                               // (uniform) pair 0: its grid is the moments' grid
+    for (int i = tid; i < 16 * BT; i += 256) {
+        const int e = i / BT, b2 = i - e * BT;
+        const int j = e >> 2, k = e & 3;
+        float2 v;
+        if (j == 3 && k == 3) v = make_float2(fB, 0.f);
+        else if (j == 3 || k == 3) {
+            const int d = j == 3 ? k : j;
+            const float2 sd = mom[d * BT + b2], kd = Kl[d * BT + b2];
+            v = make_float2(kd.x + sd.x * iB, kd.y + sd.y * iB);                     // the mean
+            if (j == 3) v.y = -v.y;
+        } else {
+            const int lo = j < k ? j : k, hi = j < k ? k : j;
+            const int idx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);                   // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            float2 m2 = mom[(3 + idx) * BT + b2];
+            const float2 sl = mom[lo * BT + b2], sh2 = mom[hi * BT + b2];
+            float2 c = make_float2(0.f, 0.f);
+            cfmac(c, sl, sh2);                                                       // s_lo conj(s_hi)
+            m2.x -= c.x * iB; m2.y -= c.y * iB;
+            if (j == k) m2.y = 0.f;
+            if (j > k) m2.y = -m2.y;
+            v = m2;
+        }
+        Ms[i] = v;
+        if (store_m && s0 + b2 < q.P) g.Mout[(size_t)e * P0 + (size_t)(s0 + b2)] = v;
+    }
+    __syncthreads();
+    // ---- centre the affine columns: A~_1 = A_1 + sum_j A_j xbar_j (the same for O^) ----
+    for (int a = ry; a < dD; a += RT) {
+        float2 a3 = As[((OPC - 1) * dD + a) * BT + bl], o3 = Os[((OPC - 1) * dD + a) * BT + bl];
+#pragma unroll
+        for (int j = 0; j < OPC - 1; ++j) {
+            const float2 xb = Ms[(j * OPC + 3) * BT + bl];
+            cfma2(a3, As[(j * dD + a) * BT + bl], xb);
+            cfma2(o3, Os[(j * dD + a) * BT + bl], xb);
+        }
+        As[((OPC - 1) * dD + a) * BT + bl] = a3; Os[((OPC - 1) * dD + a) * BT + bl] = o3;
+    }
+    __syncthreads();
+    for (int a = ry; a < dD; a += RT) {
+        float2 E[OPC], U[OPC];
+#pragma unroll
+        for (int j = 0; j < OPC; ++j) { const float2 av = As[(j * dD + a) * BT + bl], ov = Os[(j * dD + a) * BT + bl]; E[j] = make_float2(ov.x - av.x, ov.y - av.y); }
+#pragma unroll
+        for (int k = 0; k < OPC - 1; ++k) {
+            U[k] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < OPC - 1; ++j) cfma2(U[k], E[j], Ms[(j * OPC + k) * BT + bl]);
+        }
+        U[OPC - 1] = make_float2(E[OPC - 1].x * fB, E[OPC - 1].y * fB);
+        if (!ok) continue;
+        if (s == 0) { q.es[2 * a] = U[OPC - 1].x; q.es[2 * a + 1] = U[OPC - 1].y; }
+        float2* dst = q.S + (long)a * dD * q.P + s;
+#pragma unroll 4
+        for (int b = 0; b < dD; ++b) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) cfmac(acc, U[k], As[(k * dD + b) * BT + bl]);
+            dst[(long)b * q.P] = acc;
+        }
     }
 }
-hipError_t launch_sgrad_group(SgradGroup& g, hipStream_t st)
+static int msgrad_bt(int dD) { return dD <= 4 ? 64 : (dD <= 8 ? 32 : (dD <= 16 ? 16 : 8)); }
+hipError_t launch_msgrad_group(SgradGroup& g, hipStream_t st)
 {
-    if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
+    if (g.n < 1 || g.n > 8 || !g.Xf || g.B < 1 || g.D0 < 1 || g.D0 > OPC - 1 || g.P0 >= (1L << 28)) return hipErrorInvalidValue;
     long total = 0;
-    for (int i = 0; i < g.n; ++i) {
+    size_t lds = 0;
+    for (int i = g.n - 1; i >= 0; --i) {                               // (start[] is DEscending in i: see the kernel's lookup)
+        const int bt = msgrad_bt(g.q[i].dD);
+        g.bt[i] = bt;
         g.start[i] = (int)total;
-        total += ((g.q[i].P + 63) / 64) * ((g.q[i].dD + 3) / 4) * ((g.q[i].dD + 7) / 8);
+        total += (g.q[i].P + bt - 1) / bt;
+        lds = std::max(lds, sizeof(float2) * (std::max((size_t)2 * OPC * g.q[i].dD * bt, (size_t)9 * 256) + (size_t)(9 + 3 + 16) * bt));
     }
-    if (total >= (1L << 31)) return hipErrorInvalidValue;
+    if (total >= (1L << 31) || lds > 150 * 1024) return hipErrorInvalidValue;
     g.start[g.n] = (int)total;
-    sgrad_kernel<<<dim3((unsigned)total), dim3(64, 4), 0, st>>>(g);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    msgrad_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 
@@ -378,14 +459,7 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
                 r[k] = make_float2(av.x - r[k].x * idD, av.y - r[k].y * idD);
             }
             if (s == 0) r[OPC - 1].x -= q.p[a] * NN;
-            // sum_{k,k'} r[k] M^[k][k'] conj(r[k'])  (real)
-#pragma unroll
-            for (int k = 0; k < OPC; ++k) {
-                float2 v = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int k2 = 0; k2 < OPC; ++k2) cfmac(v, Ms[(k * OPC + k2) * BT + bl], r[k2]);
-                part += r[k].x * v.x - r[k].y * v.y;
-            }
+            part += quad_centred(r, [&](int e) { return Ms[e * BT + bl]; });
         }
         const int nyr = q.Ny / 2 + 1;
         const int j = (int)((unsigned)sc % (unsigned)nyr);
@@ -409,7 +483,6 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
 // small products run out of LDS.  Workgroup = 32 bins x 8 row threads.
 // element `e` of a uniform base with a 32-bit BYTE offset: the load takes the scalar-base + 32-bit lane offset form (callers
 // guarantee e * 8 < 2^32)
-__device__ __forceinline__ float2 ld8(const float2* base, unsigned e) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + e * 8u); }
 
 template <int DM>
 __device__ __forceinline__ void opmse_small_body(const OpMseGroup& g, int p, float2* sh)
@@ -485,20 +558,15 @@ __device__ __forceinline__ void opmse_small_body(const OpMseGroup& g, int p, flo
             r[k] = make_float2(av.x - r[k].x * idD, av.y - r[k].y * idD);
         }
         if (s == 0) r[OPC - 1].x -= q.p[a] * NN;
-        // r M^ r^H = sum_k M[k][k] |r_k|^2 + 2 sum_{k<k2} Re( r_k M[k][k2] conj(r_k2) )
-        {
-            int e = 0;
-#pragma unroll
-            for (int k = 0; k < OPC; ++k) {
-                part += Mu[e++].x * (r[k].x * r[k].x + r[k].y * r[k].y);
-#pragma unroll
-                for (int k2 = k + 1; k2 < OPC; ++k2) {
-                    float2 v = make_float2(0.f, 0.f);
-                    cfmac(v, Mu[e++], r[k2]);                            // M[k][k2] conj(r_k2)
-                    part += 2.f * (r[k].x * v.x - r[k].y * v.y);
-                }
-            }
-        }
+        // (upper triangle of the stored M^ in Mu, row-major: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3); the lower one is its conjugate)
+        part = quad_centred(r, [&](int e) {
+            const int j = e >> 2, k = e & 3;
+            const int lo = j < k ? j : k, hi = j < k ? k : j;
+            const int idx = lo == 0 ? hi : (lo == 1 ? 3 + hi : (lo == 2 ? 5 + hi : 9));
+            float2 v = Mu[idx];
+            if (j > k) v.y = -v.y;
+            return v;
+        });
         const int nyr = q.Ny / 2 + 1;
         const int j = (int)((unsigned)sc % (unsigned)nyr);
         part *= !ok ? 0.f : ((j > 0 && j < nyr - 1) ? 2.f : 1.f);
@@ -537,13 +605,7 @@ __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t)
         float2 r[OPC];
 #pragma unroll
         for (int k = 0; k < OPC; ++k) { const float2 av = Va[a * OPC + k], fv = Vc[a * OPC + k]; r[k] = make_float2(av.x - fv.x, av.y - fv.y); }
-#pragma unroll
-        for (int k = 0; k < OPC; ++k) {
-            float2 v = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int k2 = 0; k2 < OPC; ++k2) cfmac(v, g.Mhat[(long)(k * OPC + k2) * g.P0 + u], r[k2]);
-            part += r[k].x * v.x - r[k].y * v.y;
-        }
+        part = quad_centred(r, [&](int e) { return g.Mhat[(long)e * g.P0 + u]; });
         const int nyr = q.Ny / 2 + 1;
         const int j = (int)((unsigned)t % (unsigned)nyr);
         part *= (j > 0 && j < nyr - 1) ? 2.f : 1.f;
@@ -655,11 +717,6 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
     extern __shared__ float2 Wl[];                                   // planar tiles: two V tiles [rows][OPC][CH_BT]
     const int tid = threadIdx.x;
     const int L = g.L;
-    if ((int)blockIdx.x >= g.tile_start[L]) {
-        // trailing workgroups: the batch's second moments (independent of the chain: they share the launch)
-        moment_body(g.mom_Xf, g.mom_M, g.mom_B, g.D0, g.lv[0].P, (long)blockIdx.x - g.tile_start[L], tid & 63, tid >> 6);
-        return;
-    }
     if ((long)blockIdx.x < g.Pc) {
         __shared__ float2 V[2][CH_VMAX * OPC];
         const int t = blockIdx.x;
@@ -747,7 +804,6 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
     long total = g.Pc;
     for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
     g.tile_start[g.L] = (int)total;
-    if (g.mom_Xf) total += (g.lv[0].P + 63) / 64;
     if (total >= (1L << 31)) return hipErrorInvalidValue;
     int rmax = OPC;
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
