@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}};
 static void flags_from_env_once()
 {
     static bool done = false;
@@ -264,7 +264,7 @@ static int chk_size(aefft_ctx* ctx, int Nx, int Ny)
 }
 
 // R2C (+ fused crop to Nxs x Nys).  The two kernels are bracketed separately for profiling.
-static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys, int ws_id = WS_MID)
+static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys, int ws_id = WS_MID, hipEvent_t done = nullptr)
 {
     RET_IF(chk_size(ctx, Nx, Ny));
     if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
@@ -282,7 +282,7 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c rows", e);
     {
         Bracket br(ctx, KID_R2C_COLS, b_mid + b_out);
-        e = launch_r2c(nullptr, X, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur);
+        e = launch_r2c(nullptr, X, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur, done);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c cols", e);
     return AEFFT_OK;
@@ -899,6 +899,9 @@ struct Pair {
     float* Q = nullptr;      // [dD][dD][Qn][T*T], T = 2Nk-1: pruned inverse transform of S (weight_kernels.hip), Qn row-chunk partial sums
     int Qn = 1;
     float2* Oc = nullptr;    // [B][dD][Pc] decoder output on the support of the up-sampled spectra (the coarsest pair's grid); last pair: == O
+    float2* opA[2] = {nullptr, nullptr};   // [OPC][dD][P]  operator chain: the pair's input on the basis frames, two sets (the step in progress / the next step's)
+    float2* opO[2] = {nullptr, nullptr};   // [OPC][dD][Pc] ... its decoder output on the coarsest grid's support
+    float2* Cc = nullptr;    // [dM][dD][P of the next pair] C sampled where the next pair's grid lands (operator chain: its planar tiles read nothing else of C)
     bool O_stale = false;    // the last (lazy) forward produced Oc only: expand before reading O
     float2 *X, *H, *O;       // [B][dD][P], [B][dM][P], [B][dD][P] (X aliases the previous pair's H when s == 1)
     size_t goff;             // offset (floats) of this pair's segment in the packed gradient buffer
@@ -918,6 +921,13 @@ struct aefft_net {
     float2* A0hat = nullptr;   // [OPC][D][P0] basis frames (pair 0's X in the operator form); null: D > OPC-1
     float2* Mhat = nullptr;    // [OPC][OPC][P0] second moments of the batch
     bool op_state = false;     // the activation buffers hold OPERATORS (basis-frame responses) of the last step_grad, not frames
+    // chain mode (the step's forward is chain_kernel): the operators live in their OWN buffers (Pair::opA / opO), two sets, because the
+    // tail launch of a step already runs the NEXT step's chain on the updated weights (it depends on the weights only) while the
+    // post-update MSE still reads this step's operators
+    bool op_chain = false;     // the last step_grad ran in chain mode: operators in set op_fwd, activation buffers NOT refreshed (act_stale)
+    bool act_stale = false;    // the activation buffers do not hold the last forward's frames (ensure_frames expands them from the operators)
+    bool chain_valid = false;  // set op_set holds the operators of the CURRENT weights
+    int op_set = 0, op_fwd = 0;
     float2* Wp = nullptr;      // [Pc][packE] bin-major copy of the kernel spectra the coarsest-grid chain items read (kspec_packed_kernel)
     PackArgs pack{};           // its description (static per net)
     bool packed_valid = false; // Wp belongs to the current weights
@@ -1105,7 +1115,7 @@ extern "C" int aefft_net_set_pair(aefft_net* n, int l, const float* c_h, const f
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be pageable / reused by the caller
-    q.spectra_valid = false; q.G_valid = false; n->packed_valid = false;
+    q.spectra_valid = false; q.G_valid = false; n->packed_valid = false; n->chain_valid = false;
     return AEFFT_OK;
 }
 
@@ -1175,7 +1185,7 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     HIPCHK(ctx, hipMemcpyAsync(q.b, b_h, q.dM * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(q.p, p_h, q.dD * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    q.spectra_valid = true; q.G_valid = false; n->packed_valid = false;
+    q.spectra_valid = true; q.G_valid = false; n->packed_valid = false; n->chain_valid = false;
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.C), q.c, q.dM, q.dD, q.Nk, q.Nl, q.Nx, q.Ny));
     RET_IF(aefft_kernel_export(ctx, reinterpret_cast<const float*>(q.F), q.f, q.dD, q.dM, q.Nk, q.Nl, q.Nx, q.Ny));
     return AEFFT_OK;
@@ -1213,21 +1223,56 @@ static int build_chain_items(aefft_net* n)
         if ((size_t)pa.Pc * pa.E * sizeof(float2) <= (size_t)1 << 30) {
             RET_IF(net_alloc_t(n, &n->Wp, (size_t)pa.Pc * pa.E));
             pa.Wp = n->Wp;
+            if (2 * (L - 1) <= 8)
+                for (int l = 0; l + 1 < L; ++l) RET_IF(net_alloc_t(n, &n->pr[l].Cc, (size_t)n->pr[l].dM * n->pr[l].dD * n->pr[l + 1].P));
+            for (int l = 0; l < L; ++l)
+                for (int k = 0; k < 2; ++k) {
+                    if (l > 0) RET_IF(net_alloc_t(n, &n->pr[l].opA[k], (size_t)OPC * n->pr[l].dD * n->pr[l].P));
+                    RET_IF(net_alloc_t(n, &n->pr[l].opO[k], (size_t)OPC * n->pr[l].dD * pa.Pc));
+                }
         }
     }
     return AEFFT_OK;
 }
 
+// problems of the spectra launch that serve the operator chain: Cc_l for l < L-1 (C sampled where the next pair's grid lands)
+static int cc_problems(aefft_net* n, PrunedGroup& pg, int first, double* bytes)
+{
+    int k = first;
+    for (int l = 0; l + 1 < n->L; ++l) {
+        Pair& q = n->pr[l];
+        const Pair& nx = n->pr[l + 1];
+        pg.q[k] = PrunedProb{q.c, q.Cc, (long)q.dM * q.dD, nx.Nx, nx.Ny, 1.0f, q.Nx, q.Ny};
+        if (bytes) *bytes += (double)q.dM * q.dD * (nx.P * 8.0 + q.Nk * q.Nl * 4.0);
+        ++k;
+    }
+    return k;
+}
+
+// the bin-major record Wp (and the compact Cc planes) of the CURRENT weights
 static int ensure_packed(aefft_net* n)
 {
     if (!n->Wp || n->packed_valid) return AEFFT_OK;
     aefft_ctx* ctx = n->ctx;
-    Bracket br(ctx, KID_KSPEC, (double)n->pack.Pc * n->pack.E * 8.0);
-    hipError_t e = launch_kspec_packed(n->pack, ctx->cur);
+    double bytes = (double)n->pack.Pc * n->pack.E * 8.0;
+    hipError_t e;
+    if (n->pr[0].Cc) {
+        PrunedGroup pg{};
+        pg.n = cc_problems(n, pg, 0, &bytes);
+        n->pack.upd = 0;
+        Bracket br(ctx, KID_KSPEC, bytes);
+        e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, &n->pack, nullptr);
+    } else {
+        Bracket br(ctx, KID_KSPEC, bytes);
+        e = launch_kspec_packed(n->pack, ctx->cur);
+    }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "kspec_packed", e);
     n->packed_valid = true;
     return AEFFT_OK;
 }
+
+// the training step's forward runs as ONE chain launch on the basis frames (chain_kernel) under these switches
+static bool chain_switches_ok() { return !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP)); }
 
 // The training step runs in operator form (opform_kernels.hip) when every pair has the Q-path gradient (equal square 3x3 / 5x5
 // supports with pruned transforms) and the input has at most OPC-1 channels.
@@ -1240,14 +1285,38 @@ static bool op_eligible(const aefft_net* n)
     return true;
 }
 
+// operator form: where pair l's operators of the step in progress are (A_l [OPC][dD][P], O^_l [OPC][dD][PO] on the grid nxo x nyo)
+struct OpView { const float2 *A, *O; int nxo, nyo; long PO; };
+static bool op_mode(const aefft_net* n) { return n->op_state || n->op_chain; }
+static OpView op_view(const aefft_net* n, int l)
+{
+    const Pair& q = n->pr[l];
+    if (n->op_chain) return OpView{l == 0 ? n->A0hat : q.opA[n->op_fwd], q.opO[n->op_fwd], n->NxC, n->NyC, n->Pc};
+    const bool st = q.O_stale;
+    return OpView{q.X, st ? q.Oc : q.O, st ? n->NxC : q.Nx, st ? n->NyC : q.Ny, st ? n->Pc : q.P};
+}
+static void fill_chain(aefft_net* n, ChainArgs& ca, int set, double* bytes)
+{
+    const int L = n->L;
+    const bool cc = L == 1 || n->pr[0].Cc != nullptr;
+    for (int l = 0; l < L; ++l) {
+        Pair& q = n->pr[l];
+        ca.lv[l] = ChainLevel{q.C, q.F, q.b, q.p, l == 0 ? n->A0hat : q.opA[set], q.opO[set], q.dD, q.dM, q.Nx, q.Ny, q.P, cc ? q.Cc : nullptr};
+        const double cb = (l + 1 < L) ? (double)n->pr[l + 1].P : (double)q.P;
+        if (bytes) *bytes += ((double)q.dM * q.dD * (cb + n->Pc) + (double)OPC * q.dD * (q.P + n->Pc)) * 8.0;
+    }
+    ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
+}
+
 // the reconstruction's inverse FFT (fft_backproplib.cu:1373) on ctx->cur; operator form: the per-frame spectra are expanded first
 static int launch_recon(aefft_net* n, float* recon_d, int wsid)
 {
     aefft_ctx* ctx = n->ctx;
     Pair& q = n->pr[0];
-    const float2* src = q.O_stale ? q.Oc : q.O;
-    const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
-    if (n->op_state) {
+    const OpView ov = op_mode(n) ? op_view(n, 0) : OpView{nullptr, q.O_stale ? q.Oc : q.O, q.O_stale ? n->NxC : q.Nx, q.O_stale ? n->NyC : q.Ny, 0};
+    const float2* src = ov.O;
+    const int nxo = ov.nxo, nyo = ov.nyo;
+    if (op_mode(n)) {
         // operator form: O_0,b = O^_0 [x_b; 1] is evaluated inside the column pass of the inverse transform (no stored planes)
         static_assert(OPIN_COLS == OPC, "operator width");
         const OpIn op{src, n->Xf, q.dD, q.Nx, q.Ny};
@@ -1267,14 +1336,25 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     const int L = n->L;
     struct BiasColGuard { aefft_ctx* c; ~BiasColGuard() { c->biasColP1 = 0; } } guard{ctx};
     ctx->biasColP1 = op ? (int)OPC : 0;        // conv_k biases: the affine column only
-    n->op_state = op;
     RET_IF(join_recon(ctx));
     n->xx_done = false; n->ox_done = 0;
-    // (the fused chain launch reads the innermost pair from the bin-major record Wp only: its planar spectra, which a training step
-    // in operator form does not refresh, are formed when something else asks for them)
-    const bool chain_plan = op && lazy && n->Wp && (n->compact || L == 1) &&
-        !(dev_flags & (AEFFT_F_NOCHAIN | AEFFT_F_NOLAZY | AEFFT_F_NOCOMPACT | AEFFT_F_NOGROUP | AEFFT_F_NOMFMA | AEFFT_F_NOFUSECROP));
-    for (int l = 0; l < L; ++l) if (!(chain_plan && l == L - 1 && L > 1)) RET_IF(ensure_spectra(n, n->pr[l]));
+    // the whole network on the basis frames in one launch (chain_kernel): hidden layers not materialised, decoder outputs on the
+    // coarsest grid's support, operators in their own buffers
+    const bool chain_plan = op && lazy && n->Wp && (n->compact || L == 1) && chain_switches_ok();
+    // (the chain launch reads the bin-major record Wp and the compact Cc planes only: planar spectra that a training step in operator
+    // form does not refresh are formed when something else asks for them)
+    const bool chain_cc = chain_plan && (L == 1 || n->pr[0].Cc != nullptr);
+    n->op_state = op && !chain_plan;
+    n->op_chain = chain_plan;
+    n->act_stale = chain_plan;
+    for (int l = 0; l < L; ++l) if (!(chain_cc || (chain_plan && l == L - 1 && L > 1))) RET_IF(ensure_spectra(n, n->pr[l]));
+    // the reconstruction's side stream forks behind the last launch in front of the gradient kernels -- the input transform's column
+    // pass, or the chain launch when the operators of the current weights are not at hand (first step, weights set from outside) --
+    // through that dispatch's own completion signal
+    const bool want_fork = chain_plan && recon_d && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && !ctx->prof &&
+                           !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
+    const bool need_chain = chain_plan && !n->chain_valid;
+    bool fork_recorded = false;
     // encoder (fft_backproplib.cu:1340-1357): R2C fused with pair 0's pooling, then pool -> conv per pair
     const bool prefetch = lazy && n->input_ready && n->X0alt && ctx->aux[1] != nullptr && !ctx->prof && !flag(AEFFT_F_NOPREFETCH);
     if (prefetch) {
@@ -1292,31 +1372,29 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         RET_IF(rc);
         HIPCHK(ctx, hipEventRecord(n->ev_r2c, ctx->aux[1]));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, n->ev_r2c, 0));
-    } else RET_IF(do_r2c(ctx, frames_d, n->Xf, (long)BF * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny));
-    n->pr[0].X = op ? n->A0hat : n->Xf;
-    // the whole network on the basis frames in one launch (chain_kernel) when its output layout is the one the step uses anyway:
-    // hidden layers not materialised, decoder outputs on the coarsest grid's support
-    const bool chain_ok = chain_plan;
-    bool chained = false, fork_recorded = false;
-    if (chain_ok) {
-        ChainArgs ca{};
-        double bytes = 0;
-        for (int l = 0; l < L; ++l) {
-            Pair& q = n->pr[l];
-            ca.lv[l] = ChainLevel{q.C, q.F, q.b, q.p, q.X, q.P != n->Pc ? q.Oc : q.O, q.dD, q.dM, q.Nx, q.Ny, q.P};
-            const double cb = (l + 1 < L) ? (double)n->pr[l + 1].P : (double)q.P;
-            bytes += ((double)q.dM * q.dD * (cb + n->Pc) + (double)OPC * q.dD * (q.P + n->Pc)) * 8.0;
-            q.H_stale = true; q.O_stale = q.P != n->Pc;
+    } else {
+        const bool fork_r2c = want_fork && !need_chain;
+        RET_IF(do_r2c(ctx, frames_d, n->Xf, (long)BF * n->D, n->Nx, n->Ny, n->pr[0].Nx, n->pr[0].Ny, WS_MID, fork_r2c ? ctx->ev_fork : nullptr));
+        fork_recorded = fork_r2c;
+    }
+    n->pr[0].X = n->op_state ? n->A0hat : n->Xf;
+    bool chained = false;
+    if (chain_plan) {
+        if (need_chain) {
+            RET_IF(ensure_packed(n));
+            ChainArgs ca{};
+            double bytes = 0;
+            fill_chain(n, ca, n->op_set, &bytes);
+            Bracket br(ctx, KID_CHAIN, bytes);
+            const bool fork_here = want_fork && !fork_recorded;
+            hipError_t e = launch_chain(ca, ctx->cur, fork_here ? ctx->ev_fork : nullptr);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
+            fork_recorded = fork_recorded || fork_here;
+            n->chain_valid = true;
         }
-        RET_IF(ensure_packed(n));
-        ca.L = L; ca.D0 = n->D; ca.Pc = n->Pc; ca.Wp = n->Wp; ca.E = n->pack.E;
-        Bracket br(ctx, KID_CHAIN, bytes);
-        // the reconstruction's side stream forks right behind this launch (below): its completion signal is the fork event
-        const bool fork_here = recon_d && lazy && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && !ctx->prof &&
-                               !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
-        hipError_t e = launch_chain(ca, ctx->cur, fork_here ? ctx->ev_fork : nullptr);
-        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "chain", e);
-        chained = true; fork_recorded = fork_here;
+        n->op_fwd = n->op_set;
+        for (int l = 0; l < L; ++l) { Pair& q = n->pr[l]; q.H_stale = true; q.O_stale = q.P != n->Pc; }      // (what ensure_frames leaves in the activation buffers)
+        chained = true;
     }
     for (int l = 0; l < L && !chained; ++l) {
         Pair& q = n->pr[l];
@@ -1447,7 +1525,33 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
 // so the per-frame forward of the same frames is run first (with the CURRENT weights; the step's gradient state is kept).
 static int ensure_frames(aefft_net* n)
 {
+    if (n->op_chain && n->act_stale) {
+        // chain mode: X_l,b = A_l [x_b; 1], O_l,b = O^_l [x_b; 1] from the RESIDENT input spectra and the operators of the last
+        // step_grad (set op_fwd: intact until the step after next's tail launch) -- neither the caller's frame buffer nor the
+        // current (possibly updated) weights enter.  Hidden layers stay to be formed on request (H_stale).
+        aefft_ctx* ctx = n->ctx;
+        const Pair& q0 = n->pr[0];
+        for (int l = 0; l < n->L; ++l) {
+            Pair& q = n->pr[l];
+            hipError_t e = hipSuccess;
+            if (l > 0) {
+                Bracket br(ctx, KID_OPFORM, ((double)OPC * q.dD + (double)n->B * (q.dD + n->D)) * q.P * 8.0);
+                e = launch_op_expand(q.opA[n->op_fwd], n->Xf, q.X, n->B, n->D, q.dD, q0.Nx, q0.Ny, q.Nx, q.Ny, ctx->cur);
+            }
+            if (e == hipSuccess) {
+                Bracket br(ctx, KID_OPFORM, ((double)OPC * q.dD + (double)n->B * (q.dD + n->D)) * n->Pc * 8.0);
+                e = launch_op_expand(q.opO[n->op_fwd], n->Xf, q.P != n->Pc ? q.Oc : q.O, n->B, n->D, q.dD, q0.Nx, q0.Ny, n->NxC, n->NyC, ctx->cur);
+            }
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "op_expand", e);
+            q.H_stale = true; q.O_stale = q.P != n->Pc;
+        }
+        n->pr[0].X = n->Xf;
+        n->act_stale = false;
+        return AEFFT_OK;
+    }
     if (!n->op_state) return AEFFT_OK;
+    // (operator form without the chain launch: the activation buffers hold the operators themselves; the per-frame forward of the
+    // same frames is run -- the caller's frame buffer must still hold them, include/aefft.h)
     const bool hg = n->have_grad;
     RET_IF(net_forward(n, n->last_frames, nullptr, false, false));
     n->have_grad = hg;
@@ -1478,6 +1582,7 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
             c = q.dM; S = q.H;
             if (out_d && q.H_stale) {          // hidden layer skipped by the training step's forward: form it now (fft_backproplib.cu:1347)
                 Pair& qm = n->pr[(layer - 1) / 2];
+                RET_IF(ensure_spectra(n, qm));
                 RET_IF(do_conv(n->ctx, qm.X, qm.C, qm.b, qm.H, n->B, qm.dM, qm.dD, qm.Nx, qm.Ny));
                 qm.H_stale = false;
             }
@@ -1585,6 +1690,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     RET_IF(join_recon(ctx));
     RET_IF(ensure_frames(n));
     Pair& q = n->pr[l];
+    RET_IF(ensure_spectra(n, q));
     RET_IF(ensure_O(n, q));
     if ((size_t)(n_iter + 1) > n->mse_cap) {
         float* nm;
@@ -1613,7 +1719,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
         HIPCHK(ctx, hipMemcpyAsync(mse_h, n->mse_dev, sizeof(float) * (n_iter + 1), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    q.G_valid = false; n->packed_valid = false;         // the burst changed this pair's weights (and used S)
+    q.G_valid = false; n->packed_valid = false; n->chain_valid = false;         // the burst changed this pair's weights (and used S)
     return mark_step_point(n);
 }
 
@@ -1641,15 +1747,16 @@ static int grads_grouped(aefft_net* n)
 {
     aefft_ctx* ctx = n->ctx;
     Contract qs[8];
-    const bool op = n->op_state;
+    const bool op = op_mode(n);
     if (op) {
         // the batch moments, S_l = sum_b (O_b - X_b) X_b^H and the DC error sums of every pair from the operators: one launch
         SgradGroup sg{};
         double bytes = ((double)n->B * n->D + (double)OPC * OPC) * n->pr[0].P * 8.0;      // the input spectra in, the moments out
         for (int l = 0; l < n->L; ++l) {
             Pair& q = n->pr[l];
-            const int nxo = q.O_stale ? n->NxC : q.Nx, nyo = q.O_stale ? n->NyC : q.Ny;
-            sg.q[l] = OpPair{q.X, q.O_stale ? q.Oc : q.O, q.S, q.es, q.dD, q.Nx, q.Ny, nxo, nyo, q.P, bins(nxo, nyo)};
+            const OpView ov = op_view(n, l);
+            const int nxo = ov.nxo, nyo = ov.nyo;
+            sg.q[l] = OpPair{ov.A, ov.O, q.S, q.es, q.dD, q.Nx, q.Ny, nxo, nyo, q.P, bins(nxo, nyo)};
             bytes += ((double)OPC * q.dD * (q.P + bins(nxo, nyo)) + (double)q.dD * q.dD * q.P) * 8.0;
         }
         sg.n = n->L; sg.Xf = n->Xf; sg.Mout = n->Mhat; sg.B = n->B; sg.D0 = n->D; sg.Nx0 = n->pr[0].Nx; sg.Ny0 = n->pr[0].Ny; sg.P0 = n->pr[0].P;
@@ -1705,10 +1812,10 @@ static int grads_grouped(aefft_net* n)
             bg.a[l] = BiasGradArgs{q.O_stale ? q.Oc : q.O, q.X, q.F, q.b, qpath ? nullptr : q.df, g + 2 * nk, g + 2 * nk + q.dM, n->B, q.dM, q.dD, q.P,
                                    (float)q.Nx * (float)q.Ny, Norm, q.O_stale ? n->Pc : q.P, qpath ? q.es : nullptr, op ? q.es : nullptr};
             if (!q.spectra_valid) {
-                // (operator form, innermost pair: the step left its planar spectra stale; F at the DC bin is record 0 of the
-                // bin-major copy -- element (d1*dM + m) of the F segment, stride 1.  Only F is read through P in this form.)
-                if (!(op && qpath && l == n->L - 1 && n->Wp && n->packed_valid)) return fail(ctx, AEFFT_ESTATE, "gradient: stale kernel spectra");
-                bg.a[l].F = n->Wp + n->pack.seg[n->L].off;
+                // (operator form: the step left the planar spectra stale; F at the DC bin is record 0 of the
+                // bin-major copy -- element (d1*dM + m) of the pair's F segment, stride 1.  Only F is read through P in this form.)
+                if (!(op && qpath && n->Wp && n->packed_valid)) return fail(ctx, AEFFT_ESTATE, "gradient: stale kernel spectra");
+                bg.a[l].F = n->Wp + n->pack.seg[2 * n->L - 1 - l].off;      // (segments: C_0 .. C_{L-1}, F_{L-1} .. F_0)
                 bg.a[l].P = 1;
             }
             bbytes += ((double)(q.dM * q.dD + q.dM + q.dD) + 2.0 * n->B * q.dD) * 8.0;
@@ -1816,9 +1923,10 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
 {
     aefft_ctx* ctx = n->ctx;
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
-    n->packed_valid = false;
+    n->packed_valid = false; n->chain_valid = false;
     const bool nogroup1 = flag(AEFFT_F_NOGROUP);
     bool fused_upd = false;                                                // the tap half of the update rides with mse_finish (below)
+    bool gp_route = false;                                                 // the spectra launch wrote G' = F'.C'/(dM dD) for every pair but the innermost
     UpdateGroup wupd{};
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
     for (int l = 0; l < n->L && grouped_w; ++l) {
@@ -1835,23 +1943,28 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
             ug.a[l] = mk_update(q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
                                 q.dM, q.dD, q.Nk, q.Nl, del, sym, gscale, n->mse_post + l);
-            pg.q[l] = PrunedProb{q.c, q.C, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
             ubytes += (double)nk * 4.0 * 8;
-            kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
         }
-        ug.n = pg.n = n->L;
-        const bool ride = n->op_state && n->Wp != nullptr;                  // the bin-major copy for the next step's chain: same taps, same launch
+        ug.n = n->L;
+        const bool ride = op_mode(n) && n->Wp != nullptr;                  // the bin-major copy for the next step's chain: same taps, same launch
         // Fused update (operator form, plain gradients): no update launch.  The spectra launch reads every tap THROUGH the pending
         // update (w - clip_step(g, D): TapUpd) and carries the bias half as a trailing workgroup per pair; the taps and their momentum
         // are stored in place by trailing workgroups of the step's last launch (mse_finish) -- nothing in between reads them.
         fused_upd = ride && !sym && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
+        // Operator form with the chain launch: NO planar spectra are written.  The next step's chain reads the bin-major record Wp
+        // and the compact planes Cc_l (C_l where the next pair's grid lands); the post-update MSE reads G'_l = F'_l.C'_l/(dM dD) --
+        // dD*dD planes per pair, the spectrum of the (2Nk-1)^2 kernel f' (*) c' whose taps the transforming workgroups form
+        // themselves (gspec_gbody) -- and the innermost pair from Wp.  Planar C|F are formed when something else asks (ensure_spectra).
+        gp_route = ride && n->pr[0].Cc != nullptr && 2 * (n->L - 1) <= 8 && chain_switches_ok() && n->compact &&
+                   n->pr[n->L - 1].P == n->pack.Pc && n->pr[n->L - 1].dD <= CH_VMAX && n->pr[n->L - 1].dM <= CH_VMAX;
         BiasUpdGroup bu{};
+        TapUpd tu[8] = {};
         if (fused_upd) {
             for (int l = 0; l < n->L; ++l) {
                 Pair& q = n->pr[l];
                 float* g = n->grad + q.goff;
                 const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
-                pg.upd[l] = TapUpd{g, q.Dc, ug.a[l].del, ug.a[l].alpha, ug.a[l].gscale};        // (c|f, dck|dfk, Dc|Df: each pair contiguous)
+                tu[l] = TapUpd{g, q.Dc, ug.a[l].del, ug.a[l].alpha, ug.a[l].gscale};        // (c|f, dck|dfk, Dc|Df: each pair contiguous)
                 bu.a[l] = BiasUpd{q.b, q.p, q.Db, q.Dp, g + 2 * nk, g + 2 * nk + q.dM, n->mse_post + l, q.dM, q.dD};
             }
             bu.n = n->L; bu.del = ug.a[0].del; bu.alpha = ug.a[0].alpha; bu.gscale = ug.a[0].gscale;
@@ -1863,34 +1976,60 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             hipError_t e = launch_update_group(ug, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e);
         }
-        // Operator form: nothing in a training step reads the innermost pair's PLANAR spectra (the chain, the post-update MSE and
-        // the DC-bin gradient terms take that pair from the bin-major record): they are left stale (a fifth of the bytes of this
-        // launch) and formed on demand (ensure_spectra) by whatever else asks for them.
-        const bool skip_inner = ride && n->L > 1 && n->pr[n->L - 1].P == n->pack.Pc && n->pr[n->L - 1].dD <= CH_VMAX && n->pr[n->L - 1].dM <= CH_VMAX &&
-                                !flag(AEFFT_F_NOCHAIN) && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
-        if (skip_inner) {
-            const Pair& qi = n->pr[n->L - 1];
-            pg.n = n->L - 1;
-            kbytes -= 2.0 * qi.dM * qi.dD * (qi.P * 8.0 + qi.Nk * qi.Nl * 4.0);
+        bool skip_inner = false;
+        if (gp_route) {
+            int k = 0;
+            for (int l = 0; l + 1 < n->L; ++l) {
+                Pair& q = n->pr[l];
+                pg.q[k] = PrunedProb{nullptr, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f, 0, 0};
+                pg.gsrc[k] = GtapSrc{q.c, q.f, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};
+                pg.upd[k] = tu[l];
+                kbytes += (double)q.dD * q.dD * q.P * 8.0 + 2.0 * q.dM * q.dD * q.Nk * q.Nl * 4.0;
+                ++k;
+            }
+            const int k0 = k;
+            k = cc_problems(n, pg, k0, &kbytes);
+            for (int l = 0; l + 1 < n->L; ++l) pg.upd[k0 + l] = tu[l];
+            pg.n = k;
+        } else {
+            for (int l = 0; l < n->L; ++l) {
+                Pair& q = n->pr[l];
+                pg.q[l] = PrunedProb{q.c, q.C, 2L * q.dM * q.dD, q.Nx, q.Ny, 1.0f};
+                pg.upd[l] = tu[l];
+                kbytes += 2.0 * q.dM * q.dD * (q.P * 8.0 + q.Nk * q.Nl * 4.0);
+            }
+            pg.n = n->L;
+            // Without the compact planes: the innermost pair's PLANAR spectra are not written (the chain, the post-update MSE and the
+            // DC-bin gradient terms take that pair from the bin-major record)
+            skip_inner = ride && n->L > 1 && n->pr[n->L - 1].P == n->pack.Pc && n->pr[n->L - 1].dD <= CH_VMAX && n->pr[n->L - 1].dM <= CH_VMAX &&
+                         !flag(AEFFT_F_NOCHAIN) && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
+            if (skip_inner) {
+                const Pair& qi = n->pr[n->L - 1];
+                pg.n = n->L - 1;
+                kbytes -= 2.0 * qi.dM * qi.dD * (qi.P * 8.0 + qi.Nk * qi.Nl * 4.0);
+            }
         }
         hipError_t e;
         {
-            Bracket br(ctx, KID_KSPEC, kbytes + ((n->op_state && n->Wp) ? (double)n->pack.Pc * n->pack.E * 8.0 : 0.0));
+            Bracket br(ctx, KID_KSPEC, kbytes + ((op_mode(n) && n->Wp) ? (double)n->pack.Pc * n->pack.E * 8.0 : 0.0));
             e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, ride ? &n->pack : nullptr, fused_upd ? &bu : nullptr);
             if (e == hipSuccess && ride) n->packed_valid = true;
             if (e == hipSuccess && skip_inner) n->pr[n->L - 1].spectra_valid = false;
+            if (e == hipSuccess && gp_route) for (auto& q : n->pr) q.spectra_valid = false;
+            if (e == hipSuccess && !gp_route) for (int l = 0; l < pg.n; ++l) n->pr[l].spectra_valid = true;
         }
-        pg.n = n->L;
         n->pack.upd = 0;
         if (e != hipSuccess) {
             if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "kspec(group)", e);
             (void)hipGetLastError();
+            gp_route = false;
             if (fused_upd) {                                               // declined before anything ran: the separate update after all
                 fused_upd = false;
                 hipError_t e2 = launch_update_group(ug, ctx->cur);
                 if (e2 != hipSuccess) return fail(ctx, AEFFT_EHIP, "update(group)", e2);
             }
             for (int l = 0; l < n->L; ++l) RET_IF(pair_spectra(n, n->pr[l]));
+            for (auto& q : n->pr) q.spectra_valid = true;
         }
     } else for (int l = 0; l < n->L; ++l) {
         Pair& q = n->pr[l];
@@ -1899,31 +2038,49 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         RET_IF(do_update(ctx, q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
                          q.dM, q.dD, q.Nk, q.Nl, del, maxdiff, sym, gscale, n->mse_post + l));
         RET_IF(pair_spectra(n, q));
+        q.spectra_valid = true;
     }
-    if (n->op_state && n->Wp) RET_IF(ensure_packed(n));     // the next step's chain reads the bin-major copy of the NEW weights
-    if (n->op_state) {
+    if (op_mode(n) && n->Wp) RET_IF(ensure_packed(n));     // the next step's chain reads the bin-major copy of the NEW weights
+    if (op_mode(n)) {
         // post-update MSE (fft_backproplib.cu:1460-1463) in operator form: R = A - F'(C' A / dM + b^) / dD - p^ per bin, then
-        // sum_a R[a] M^ R[a]^H; the updated spectra are read once, nothing is stored (opform_kernels.hip)
+        // sum_a R[a] M^ R[a]^H; the updated spectra (or their product G') are read once, nothing is stored (opform_kernels.hip)
         OpMseGroup og{};
         double bytes = 0;
+        const bool inner_packed = n->Wp && n->packed_valid && n->pr[n->L - 1].P == n->pack.Pc;
         for (int l = 0; l < n->L; ++l) {
             Pair& q = n->pr[l];
             const float scale = 1.0f / ((float)(2 * q.dM) * (float)q.Nx * (float)q.Ny * (float)n->B) / ((float)q.dD * q.Nx * q.Ny);   // as mk_gmse
-            og.q[l] = OpMsePair{q.X, q.C, q.F, q.b, q.p, n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE, q.dD, q.dM, q.Nx, q.Ny, q.P, scale};
-            bytes += (2.0 * q.dM * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
+            OpMsePair o{};
+            o.A = op_view(n, l).A; o.C = q.C; o.F = q.F; o.b = q.b; o.p = q.p;
+            o.slots = n->mse_slots + (size_t)l * MSE_SLOTS * MSE_SLOT_STRIDE;
+            o.dD = q.dD; o.dM = q.dM; o.Nx = q.Nx; o.Ny = q.Ny; o.P = q.P; o.scale = scale;
+            if (gp_route && l + 1 < n->L) {
+                o.G = q.G; o.Fdc = n->Wp + n->pack.seg[2 * n->L - 1 - l].off; o.fdc_stride = 1;      // (F' at the DC bin: record 0 of the bin-major copy)
+                bytes += ((double)q.dD * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
+            } else {
+                if (!(l == n->L - 1 && inner_packed)) RET_IF(ensure_spectra(n, q));
+                bytes += (2.0 * q.dM * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
+            }
+            og.q[l] = o;
         }
         og.n = n->L; og.Mhat = n->Mhat; og.Nx0 = n->pr[0].Nx; og.Ny0 = n->pr[0].Ny; og.P0 = n->pr[0].P;
-        if (n->Wp && n->packed_valid && n->pr[n->L - 1].P == n->pack.Pc) {      // the innermost pair reads the bin-major copy the kspec launch just refreshed
+        if (inner_packed) {      // the innermost pair reads the bin-major copy the kspec launch just refreshed
             og.Wp = n->Wp; og.E = n->pack.E;
             og.offC = n->pack.seg[n->L - 1].off; og.offF = n->pack.seg[n->L].off;
         }
+        // The NEXT step's operator chain depends on the updated weights only (the record Wp and the planes Cc the spectra launch has just
+        // written): it shares this launch, writing the other set of operator buffers, and the next aefft_net_step_grad starts from it.
+        const bool ahead = n->op_chain && n->Wp && n->packed_valid && chain_switches_ok() && (n->compact || n->L == 1) && !flag(AEFFT_F_NOAHEAD);
+        ChainArgs ca{};
+        if (ahead) fill_chain(n, ca, n->op_set ^ 1, &bytes);
         {
             Bracket br(ctx, KID_OPMSE, bytes);
-            hipError_t e = launch_opmse_group(og, ctx->cur);
+            hipError_t e = launch_opmse_group(og, ctx->cur, ahead ? &ca : nullptr, fused_upd ? &wupd : nullptr);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "opmse", e);
         }
+        if (ahead) { n->op_set ^= 1; n->chain_valid = true; }
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, fused_upd ? &wupd : nullptr);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, nullptr);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
         return AEFFT_OK;
     }

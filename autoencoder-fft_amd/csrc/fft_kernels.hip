@@ -22,6 +22,7 @@
 // data exchanged through LDS between passes (padded index n + n/8 against bank conflicts).
 #include "internal.h"
 #include "device_util.h"
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <vector>
 
@@ -538,12 +539,14 @@ template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, l
     c2r_rows_kernel<N><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(mid, out, npairs, Wc, scale);
     return hipGetLastError();
 }
-template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st)
+template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st, hipEvent_t done)
 {
     const size_t lds = sizeof(float2) * (CW * pad_len(N));
     hipError_t e = allow_lds(fwd_cols_kernel<N, CW>, lds);
     if (e != hipSuccess) return e;
-    fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
+    // `done`: recorded by this dispatch's own completion signal (no marker packet behind it on the stream: a side stream forks here)
+    if (done) hipExtLaunchKernelGGL((fwd_cols_kernel<N, CW>), dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st, nullptr, done, 0, mid, out, Wc, Nxs);
+    else fwd_cols_kernel<N, CW><<<dim3((unsigned)planes, Wc / CW), dim3(CW * N / 8), lds, st>>>(mid, out, Wc, Nxs);
     return hipGetLastError();
 }
 static OpIn g_opin_none{};
@@ -557,7 +560,7 @@ template <int N, int CW> static hipError_t run_inv_cols(const float2* in, float2
 }
 
 // column tile width: at most 16, at most Wc, and CW*N/8 <= 1024 threads
-template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, float2* b, long planes, int Wc, int Nother, hipStream_t st, const OpIn& op = g_opin_none)
+template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, float2* b, long planes, int Wc, int Nother, hipStream_t st, const OpIn& op = g_opin_none, hipEvent_t done = nullptr)
 {
     constexpr int CWMAX = (8192 / N) < 16 ? (8192 / N) : 16;
     int cw = CWMAX;
@@ -567,7 +570,7 @@ template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, floa
     if (!FWD) while (cw > 4 && planes * (Wc / cw) < 256) cw >>= 1;
 #define AEFFT_CW_CASE(C)                                                                                   \
     if constexpr (C <= CWMAX) {                                                                             \
-        if (cw == C) return FWD ? run_fwd_cols<N, C>(a, b, planes, Wc, Nother, st) : run_inv_cols<N, C>(a, b, planes, Wc, Nother, st, op); \
+        if (cw == C) return FWD ? run_fwd_cols<N, C>(a, b, planes, Wc, Nother, st, done) : run_inv_cols<N, C>(a, b, planes, Wc, Nother, st, op); \
     }
     AEFFT_CW_CASE(16) AEFFT_CW_CASE(8) AEFFT_CW_CASE(4)
 #undef AEFFT_CW_CASE
@@ -589,7 +592,7 @@ template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, floa
     }
 
 // `in` non-null: run the row pass (in -> mid); `out` non-null: run the column pass (mid -> out).
-hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st)
+hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st, hipEvent_t done)
 {
     if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxs > Nx || Nys > Ny || Nys < 8 || Nxs < 2 || (Nys & 1) || (Nxs & 1))
         return hipErrorInvalidValue;
@@ -602,7 +605,7 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
         if (e != hipSuccess) return e;
     }
     if (out) {
-        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, true>(mid, out, planes, Wc, Nxs, st)); break)
+        AEFFT_N_SWITCH(Nx, e = (cols_dispatch<NN, true>(mid, out, planes, Wc, Nxs, st, g_opin_none, done)); break)
     }
     return e;
 }

@@ -22,7 +22,7 @@ bool fft_size_supported(int n);
 // fft.cu:87 `resize` down-sampling to Nxs x Nys).  in [planes][Nx][Ny] real ->
 // out [planes][Nxs][Nys/2+1] complex.  `mid` is a workspace of planes*Nx*(Nys/2) complex.
 hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny,
-                      int Nxs, int Nys, hipStream_t st);
+                      int Nxs, int Nys, hipStream_t st, hipEvent_t done = nullptr /* recorded by the column pass's own completion signal */);
 // Batched 2-D C2R with optional fused spectral zero-pad (== `resize` up-sampling from
 // Nxi x Nyi, then cufftExecC2R, then * scale).  in [planes][Nxi][Nyi/2+1] -> out [planes][Nx][Ny].
 // opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
@@ -110,7 +110,12 @@ hipError_t launch_kspec(const float* k, float2* K, const float2* tw, long planes
 hipError_t launch_kgrad(const float2* D, float* g, float* part /*workspace: kgrad_partial_floats()*/, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, float scale, hipStream_t st);
 size_t kgrad_partial_floats(long planes, int Nx, int Ny, int Nk, int Nl);
 // The same transforms for up to 8 problems with equal (Nk, Nl) in ONE launch (kgrad: no row chunks, so no ksum pass).
-struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale; };
+struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float scale;
+                    int NxB, NyB; /* forward transform only: the grid the phases are taken on (0: the plane's own); rows / columns of the
+                                     [Nx][Ny/2+1] output are then the images of pool_fft's crop in it (map_up_row / map_up_col) */ };
+// forward transform only: the problem's planes are G' = F'.C'/(dM dD) [dD][dD] of a pair, their (2Nk-1)^2 taps formed inside the launch from
+// c | f (read through the problem's TapUpd); f == null: an ordinary problem (taps at PrunedProb::src)
+struct GtapSrc { const float* c; const float* f; int dM, dD; float scale; };
 // forward pruned transform only: the taps are read THROUGH the pending clipped-momentum update (w - clip_step(g*gscale, D)), which
 // another launch stores afterwards (update_device.h) -- g == null: taps as stored
 struct TapUpd { const float* g; const float* D; float del, alpha, gscale; };
@@ -119,6 +124,7 @@ struct BiasUpdGroup { BiasUpd a[8]; int n; float del, alpha, gscale; };      // 
 struct PrunedGroup {
     PrunedProb q[8]; int n; int start[9], ppb[8], rows[8], pblocks[8];
     TapUpd upd[8];
+    GtapSrc gsrc[8];
     // grouped inverse transform only: rows per slice; chunks[p] in: row chunks dst has room for ([planes][chunks][taps], 0/1 = none),
     // out: the chunks the launch used (the consumer adds them in order)
     int rb[8], chunks[8];
@@ -169,16 +175,23 @@ hipError_t launch_recon_expand(const float2* O0, const float2* Xf, float2* Of, i
 hipError_t launch_op_expand(const float2* A, const float2* Xf, float2* out, int B, int D0, int dD, int Nx0, int Ny0, int Nx, int Ny, hipStream_t st);
 struct OpMsePair {
     const float2 *A, *C, *F;   // A_l [OPC][dD][P]; the UPDATED kernel spectra C [dM][dD][P], F [dD][dM][P]
+    const float2* G;           // nullable: G' = F.C/(dM dD) [dD][dD][P] of the updated weights -- then C and F are not read (opmse_gbody) ...
+    const float2* Fdc; long fdc_stride;   // ... except F at the DC bin: element (a, m) at Fdc[(a*dM + m) * fdc_stride]
     const float *b, *p;        // updated biases
     float* slots;              // MSE_SLOTS accumulators (launch_mse_finish sums them)
     int dD, dM, Nx, Ny; long P;
     float scale;               // 1 / (2 dM Nx Ny B) / (dD Nx Ny)
 };
-struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8]; const float2* Mhat; int Nx0, Ny0; long P0;
+struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8], base; const float2* Mhat; int Nx0, Ny0; long P0;
                     const float2* Wp; int E, offC, offF; /* nullable: bin-major record of the UPDATED spectra; offsets of the innermost pair's C, F in it */ };
-hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st);
+struct ChainArgs;
+struct UpdateGroup;
+// the MSE of every pair; optionally in the same launch: the operator chain of the NEXT step (chain, reading the just-written Wp / Cc, writing its own
+// operator buffers) and the tap half of a fused update (weights_upd) -- tail_kernel
+hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st, ChainArgs* chain = nullptr, const UpdateGroup* weights_upd = nullptr);
 // the network on the basis frames in one launch (chain_kernel): per pair the spectra, biases and the operator outputs
-struct ChainLevel { const float2 *C, *F; const float *b, *p; float2 *A /*[OPC][dD][P]*/, *O /*[OPC][dD][Pc]*/; int dD, dM, Nx, Ny; long P; };
+struct ChainLevel { const float2 *C, *F; const float *b, *p; float2 *A /*[OPC][dD][P]*/, *O /*[OPC][dD][Pc]*/; int dD, dM, Nx, Ny; long P;
+                    const float2* Cc; /* nullable: C sampled at the bins the NEXT level's grid lands on, [dM][dD][P of the next level] (then C is not read) */ };
 struct ChainArgs {
     ChainLevel lv[8]; int L, D0;
     long Pc;

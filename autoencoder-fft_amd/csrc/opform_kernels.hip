@@ -477,6 +477,123 @@ __device__ __forceinline__ void opmse_body(const OpMseGroup& g, int p, float2* s
     }
 }
 
+// The same MSE from the collapsed operator G' = F'.C' / (dM dD) of the UPDATED weights ([dD][dD] planes: the spectrum of the
+// (2Nk-1)^2-tap kernel f' (*) c', written by the spectra launch -- gspec_gbody, pruned_kernels.hip):  R = (I - G') A - beta^, with
+// beta^ = Nx Ny (p' + F'(0,0) b' / dD) on the affine column at the DC bin (the two bias terms of conv_k o conv_k, fft_backproplib.cu:
+// 183-184).  dD*dD instead of 2*dM*dD planes are read, and the difference to the identity is taken on the matrix elements (1 - G'_aa)
+// before anything is multiplied by the signal.  Workgroup = BT bins x (256 / BT) row threads; the first 16 elements of a thread's row
+// of G' are requested in the same round trip as the A tile and the moments.
+__device__ __forceinline__ void opmse_gbody(const OpMseGroup& g, int p, float2* sh)
+{
+    const OpMsePair q = g.q[p];
+    const int BT = g.bt[p], RT = 256 / BT, dD = q.dD;
+    const int tid = threadIdx.x;
+    float2* As = sh;                                                 // [OPC][dD][BT]
+    float2* Ms = As + (size_t)OPC * dD * BT;                         // [OPC*OPC][BT]
+    float* red = reinterpret_cast<float*>(Ms + OPC * OPC * BT);      // [4]
+    const long s0 = ((long)blockIdx.x - g.start[p]) * BT;
+    const int bl = tid % BT, ry = tid / BT;
+    const long s = s0 + bl;
+    const bool ok = s < q.P;
+    const long sc = ok ? s : q.P - 1;
+    const int nA = OPC * dD * BT, nM = OPC * OPC * BT;
+    float2 va[4], mv[4], gpre[16];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int idx = min(w * 256 + tid, nA - 1);
+        const int kd = idx / BT, b2 = idx - kd * BT;
+        va[w] = q.A[(long)kd * q.P + min(s0 + b2, q.P - 1)];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w * 256 >= nM) break;                                    // uniform
+        const int idx = min(w * 256 + tid, nM - 1);
+        const int e = idx / BT, b2 = idx - e * BT;
+        mv[w] = g.Mhat[(long)e * g.P0 + map_up(min(s0 + b2, q.P - 1), q.Nx, q.Ny, g.Nx0, g.Ny0)];
+    }
+    {
+        // (element offsets in 32 bits off the uniform base: one address register per load in flight; launch_opmse_group checks dD*dD*P*8 < 2^32)
+        const unsigned P = (unsigned)q.P, e0 = (unsigned)(min(ry, dD - 1) * dD) * P + (unsigned)sc;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) gpre[w] = ld8(q.G, e0 + (unsigned)min(w, dD - 1) * P);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int idx = w * 256 + tid; if (idx < nA) As[idx] = va[w]; }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int idx = w * 256 + tid; if (idx < nM) Ms[idx] = mv[w]; }
+    for (int i0 = 1024; i0 < nA; i0 += 1024) {
+        float2 wa[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int idx = min(i0 + w * 256 + tid, nA - 1);
+            const int kd = idx / BT, b2 = idx - kd * BT;
+            wa[w] = q.A[(long)kd * q.P + min(s0 + b2, q.P - 1)];
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int idx = i0 + w * 256 + tid; if (idx < nA) As[idx] = wa[w]; }
+    }
+    __syncthreads();
+    const float NN = (float)q.Nx * (float)q.Ny;
+    float part = 0.f;
+    // one row a of R = (I - G') A - beta^ and its quadratic form; FIRST: the row whose first 16 elements of G' were requested up front
+    auto row = [&](const int a, auto FIRST) {
+        float2 r[OPC];
+#pragma unroll
+        for (int k = 0; k < OPC; ++k) r[k] = make_float2(0.f, 0.f);
+        const float2* Gp = q.G + (long)a * dD * q.P + sc;
+        auto use = [&](int d, float2 gv) {
+            const float2 im = make_float2((d == a ? 1.f : 0.f) - gv.x, -gv.y);          // (I - G')[a][d]
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) cfma2(r[k], im, As[(k * dD + d) * BT + bl]);
+        };
+        int d0 = 0;
+        if constexpr (decltype(FIRST)::value) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                if (w < dD) use(w, gpre[w]);
+                if (w & 1) __builtin_amdgcn_sched_barrier(0);       // (keeps the LDS reads of all 16 uses from being hoisted into live registers)
+            }
+            d0 = 16;
+        }
+        auto grp = [&](int dd, auto NU) {
+            constexpr int U = decltype(NU)::value;
+            float2 gv[U];
+#pragma unroll
+            for (int w = 0; w < U; ++w) gv[w] = Gp[(long)(dd + w) * q.P];
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                use(dd + w, gv[w]);
+                if (w & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (; d0 + 8 <= dD; d0 += 8) grp(d0, std::integral_constant<int, 8>{});
+        if (d0 + 4 <= dD) { grp(d0, std::integral_constant<int, 4>{}); d0 += 4; }
+        if (d0 + 2 <= dD) { grp(d0, std::integral_constant<int, 2>{}); d0 += 2; }
+        if (d0 < dD) grp(d0, std::integral_constant<int, 1>{});
+        if (s == 0) {
+            // beta[a] = p'[a] + sum_m F'[a][m](0,0) b'[m] / dD  (F' at the DC bin is real: the sum of the taps)
+            float acc = 0.f;
+            for (int m = 0; m < q.dM; ++m) acc = fmaf(q.Fdc[((long)a * q.dM + m) * q.fdc_stride].x, q.b[m], acc);
+            r[OPC - 1].x -= (q.p[a] + acc / (float)dD) * NN;
+        }
+        if (ok) {
+            const int nyr = q.Ny / 2 + 1;
+            const int j = (int)((unsigned)sc % (unsigned)nyr);
+            part += quad_centred(r, [&](int e) { return Ms[e * BT + bl]; }) * ((j > 0 && j < nyr - 1) ? 2.f : 1.f);      // Hermitian half-plane: interior columns count twice
+        }
+    };
+    if (ry < dD) row(ry, std::true_type{});
+    for (int a = ry + RT; a < dD; a += RT) row(a, std::false_type{});
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tot != 0.f) atomicAdd(q.slots + (blockIdx.x % MSE_SLOTS) * MSE_SLOT_STRIDE, tot * q.scale);
+    }
+}
+
 // Pairs with few maps (dM == DM = 8, dD <= 4: the outermost pair, which has the most bins): the generic body spends its time in
 // three dependent memory round trips separated by barriers for a few loads each.  Here every global load of the workgroup -- the
 // A tile, this thread's row of C', its row of F', the 4x4 moments -- is issued up front (one round trip), then the same two
@@ -584,10 +701,11 @@ __device__ __forceinline__ void opmse_small_body(const OpMseGroup& g, int p, flo
 
 // The innermost pair from the bin-major copy of the updated spectra (kspec_packed_body): one workgroup per bin, C' and F' read as
 // contiguous rows (the planar layout makes them 8 K scattered 32-byte pieces per bin tile), two chain stages and the quadratic form.
-__device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t)
+constexpr size_t OPMSE_PACKED_LDS = sizeof(float2) * (3 * CH_VMAX * OPC + 2);
+__device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t, float2* sh)
 {
-    __shared__ float2 Va[CH_VMAX * OPC], Vb[CH_VMAX * OPC], Vc[CH_VMAX * OPC];
-    __shared__ float redp[4];
+    float2 *Va = sh, *Vb = sh + CH_VMAX * OPC, *Vc = sh + 2 * CH_VMAX * OPC;
+    float* redp = reinterpret_cast<float*>(sh + 3 * CH_VMAX * OPC);
     const OpMsePair q = g.q[p];
     const int dD = q.dD, dM = q.dM;
     for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; Va[i] = q.A[((long)k * dD + a) * q.P + t]; }
@@ -620,13 +738,15 @@ __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t)
     }
 }
 
-__global__ __launch_bounds__(256) void opmse_kernel(const OpMseGroup g)
+// (the bodies take their workgroup index from blockIdx.x - g.base: the launch may host other work in front, tail_kernel)
+__device__ __forceinline__ void opmse_dispatch(const OpMseGroup& g, float2* sh)
 {
-    extern __shared__ float2 sh[];                                   // As[OPC][dD][BT] | Ts[dM][OPC][BT] | red | Rs[256/BT][OPC][BT]
+    const int blk = (int)blockIdx.x - g.base;
     int p = g.n - 1;                                                 // pair n-1 owns the first workgroups, pair 0 the last
 #pragma unroll
-    for (int i = 6; i >= 0; --i) if (i < g.n - 1 && (int)blockIdx.x >= g.start[i]) p = i;
-    if (p == g.n - 1 && g.Wp) { opmse_packed(g, p, (long)blockIdx.x - g.start[p]); return; }
+    for (int i = 6; i >= 0; --i) if (i < g.n - 1 && blk >= g.start[i] - g.base) p = i;
+    if (p == g.n - 1 && g.Wp) { opmse_packed(g, p, (long)blockIdx.x - g.start[p], sh); return; }
+    if (g.q[p].G) { opmse_gbody(g, p, sh); return; }                 // (uniform) the pair's collapsed operator G' is at hand
     const int bt = g.bt[p];                                          // uniform per workgroup
     if (bt == 32) opmse_small_body<8>(g, p, sh);
     else if (bt == 16) opmse_body<16>(g, p, sh);
@@ -634,11 +754,13 @@ __global__ __launch_bounds__(256) void opmse_kernel(const OpMseGroup g)
     else opmse_body<4>(g, p, sh);
 }
 
-hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
+// workgroup ranges and LDS of the MSE part; `base` = workgroups of the launch in front of it (start[] are launch-wide indices)
+static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t* lds_out)
 {
     if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
-    long total = 0;
+    long total = base;
     size_t lds = 0;
+    g.base = base;
     for (int i = g.n - 1; i >= 0; --i) {                               // innermost (deepest K) pairs first: they are the long poles
         const OpMsePair& q = g.q[i];
         // bins per workgroup: whole 128-byte lines when the pair still yields >= 128 workgroups and its tiles fit 64 KB of LDS
@@ -646,22 +768,23 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st)
         while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
         size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2) + (size_t)OPC * OPC * bt * sizeof(float2);
         const bool pk = i == g.n - 1 && g.Wp && q.dD <= CH_VMAX && q.dM <= CH_VMAX;
-        if (!pk && q.dM == 8 && q.dD <= 4 && !flag(AEFFT_F_NOFAST)) { bt = 32; need = (size_t)OPC * (4 + 8) * 32 * sizeof(float2) + 64; }     // opmse_small_body (bt == 32 selects it)
+        if (pk) need = OPMSE_PACKED_LDS;
+        else if (q.G) {                                                  // opmse_gbody
+            if ((double)q.dD * q.dD * q.P * 8.0 >= 4294967296.0) return hipErrorInvalidValue;
+            bt = q.dD <= 4 ? 64 : (q.dD <= 8 ? 32 : (q.dD <= 16 ? 16 : 8));
+            need = sizeof(float2) * ((size_t)OPC * q.dD * bt + (size_t)OPC * OPC * bt) + 64;
+        } else if (q.dM == 8 && q.dD <= 4 && !flag(AEFFT_F_NOFAST)) { bt = 32; need = (size_t)OPC * (4 + 8) * 32 * sizeof(float2) + 64; }     // opmse_small_body (bt == 32 selects it)
         if (i == g.n - 1 && !pk) g.Wp = nullptr;
-        if (need > 150 * 1024 && !pk) return hipErrorInvalidValue;
+        if (need > 150 * 1024) return hipErrorInvalidValue;
         g.bt[i] = bt;
-        if (!pk) lds = std::max(lds, need);
+        lds = std::max(lds, need);
         g.start[i] = (int)total;
         total += pk ? q.P : (q.P + bt - 1) / bt;
     }
     if (total >= (1L << 31)) return hipErrorInvalidValue;
-    g.start[g.n] = (int)total;                                         // (start[] is DEscending in i: see opmse_kernel's lookup)
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(opmse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    opmse_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
-    return hipGetLastError();
+    g.start[g.n] = (int)total;                                         // (start[] is DEscending in i: see opmse_dispatch's lookup)
+    *nblocks = total - base; *lds_out = lds;
+    return hipSuccess;
 }
 
 }  // namespace aefft
@@ -712,14 +835,16 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 //    ancestor chain A_1 .. A_j from the PLANAR spectra (small matrices; lanes along the bins: coalesced) and stores A_j.
 // No workgroup waits for another one; the only cost of the independence is the re-evaluation of a few small products.
 constexpr int CH_BT = 8;
-__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
+constexpr size_t CHAIN_BIN_LDS = sizeof(float2) * 2 * CH_VMAX * OPC;
+// bx: the workgroup's index inside the chain part of the launch; Wl: dynamic LDS (per-bin items: two running vectors; planar tiles:
+// two V tiles [rows][OPC][CH_BT])
+__device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, float2* Wl)
 {
-    extern __shared__ float2 Wl[];                                   // planar tiles: two V tiles [rows][OPC][CH_BT]
     const int tid = threadIdx.x;
     const int L = g.L;
-    if ((long)blockIdx.x < g.Pc) {
-        __shared__ float2 V[2][CH_VMAX * OPC];
-        const int t = blockIdx.x;
+    if ((long)bx < g.Pc) {
+        float2* V[2] = {Wl, Wl + CH_VMAX * OPC};
+        const int t = bx;
         const bool dc = t == 0;
         const float2* rec = g.Wp + (long)t * g.E;
         for (int i = tid; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; V[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
@@ -737,11 +862,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
     // ---- planar tile of grid j ----
     int j = 1;
 #pragma unroll
-    for (int i = 2; i < 8; ++i) if (i < L && (int)blockIdx.x >= g.tile_start[i]) j = i;
+    for (int i = 2; i < 8; ++i) if (i < L && bx >= g.tile_start[i]) j = i;
     const int bl = tid % CH_BT, ry = tid / CH_BT;
     constexpr int RT = 256 / CH_BT;
     const ChainLevel lj = g.lv[j];
-    const long s0 = (long)(blockIdx.x - g.tile_start[j]) * CH_BT;
+    const long s0 = (long)(bx - g.tile_start[j]) * CH_BT;
     const long s = min(s0 + bl, lj.P - 1);
     const bool ok = s0 + bl < lj.P;
     long sb[8];
@@ -764,12 +889,14 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
             float2 acc[OPC];
 #pragma unroll
             for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
-            const float2* Wp = w.C + (long)r * K * w.P + sb[i - 1];
+            // (the pair's planar spectrum, or its compact copy Cc sampled where grid i lands: then bin sb[i] of planes of lv[i].P bins)
+            const long pst = w.Cc ? g.lv[i].P : w.P;
+            const float2* Wp = (w.Cc ? w.Cc + sb[i] : w.C + sb[i - 1]) + (long)r * K * pst;
             auto grp = [&](int k0, auto NU) {
                 constexpr int U = decltype(NU)::value;
                 float2 wv[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) wv[u] = Wp[(long)(k0 + u) * w.P];
+                for (int u = 0; u < U; ++u) wv[u] = Wp[(long)(k0 + u) * pst];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -793,7 +920,13 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
     }
 }
 
-hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
+{
+    extern __shared__ float2 Wl[];
+    chain_body(g, blockIdx.x, Wl);
+}
+
+static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
 {
     if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
     for (int l = 0; l < g.L; ++l) {
@@ -808,10 +941,68 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
     int rmax = OPC;
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
     g.vt_elems = rmax * OPC * CH_BT;
-    const size_t lds = sizeof(float2) * 2 * g.vt_elems;
+    *nblocks = total;
+    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS);
+    return hipSuccess;
+}
+
+hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
+{
+    long total; size_t lds;
+    const hipError_t eg = chain_geometry(g, &total, &lds);
+    if (eg != hipSuccess) return eg;
     // `done`: recorded by this dispatch's own completion signal (no marker packet behind it on the stream: a side stream forks here)
     if (done) hipExtLaunchKernelGGL(chain_kernel, dim3((unsigned)total), dim3(256), lds, st, nullptr, done, 0, g);
     else chain_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// The tail of a training step in ONE launch: the NEXT step's operator chain on the updated weights (its per-bin workgroups first:
+// eight dependent stages each), the post-update MSE of every pair, and the in-place store of the updated taps (the deferred half
+// of a fused update).  The chain reads the record Wp / the compact planes Cc that the spectra launch has just written and writes
+// the OTHER set of operator buffers; the MSE reads the operators of the step that is ending.  Nothing in the launch depends on
+// anything else in it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
+{
+    extern __shared__ float2 sh[];
+    if ((int)blockIdx.x < nchain) { chain_body(ch, blockIdx.x, sh); return; }
+    if ((int)blockIdx.x >= nupd_start) {
+        const int blk = blockIdx.x - nupd_start;
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (i < ug.n && blk >= ug.start[i]) p = i;
+        update_weights_part(ug.a[p], blk - ug.start[p]);
+        return;
+    }
+    opmse_dispatch(g, sh);
+}
+
+static UpdateGroup g_tail_ug_none{};
+static ChainArgs g_tail_chain_none{};
+// chain == null: the MSE (and the tap stores) alone
+hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st, ChainArgs* chain, const UpdateGroup* weights_upd)
+{
+    long nchain = 0, nmse = 0;
+    size_t lds_c = 0, lds_m = 0;
+    if (chain) { const hipError_t e = chain_geometry(*chain, &nchain, &lds_c); if (e != hipSuccess) return e; }
+    { const hipError_t e = opmse_geometry(g, (int)nchain, &nmse, &lds_m); if (e != hipSuccess) return e; }
+    int nupd = 0;
+    UpdateGroup ug = g_tail_ug_none;
+    if (weights_upd && weights_upd->n > 0) {
+        ug = *weights_upd;
+        for (int i = 0; i < ug.n; ++i) { ug.start[i] = nupd; nupd += (ug.a[i].dM * ug.a[i].dD * ug.a[i].Nk * ug.a[i].Nl + 255) / 256; }
+        ug.start[ug.n] = nupd;
+    }
+    const size_t lds = std::max(lds_c, lds_m);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const long total = nchain + nmse + nupd;
+    if (total >= (1L << 31)) return hipErrorInvalidValue;
+    tail_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
     return hipGetLastError();
 }
 

@@ -36,23 +36,151 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
 // Thread <-> (plane, column j); the column factor v_k = sum_l c[k][l] e^{-2 pi i j lam_l / Ny} is row independent, so
 // it is formed once per thread (25 real x complex FMAs) and every output row then costs 5 complex multiplies with
 // the row phases (LDS broadcast reads).  Consecutive threads own consecutive columns: coalesced stores.
+// The transform half of kspec_body: thread <-> column j of ONE plane whose NK*NL taps lie at `c` (LDS); rows i0 .. i0+nrows of the
+// plane at `dst` ([Nx][Nyr], j added by the caller).  (NxB, NyB): the grid the phases are taken on -- row i / column j of the
+// [Nx][Ny/2+1] output are the images map_up_row / map_up_col of pool_fft's crop in it (the spectrum sampled where the NEXT pair's
+// grid lands: the chain's planar tiles read nothing else); NxB == Nx: the plane's own grid.
+template <int NK, int NL>
+__device__ __forceinline__ void kspec_rows(const float* __restrict__ c, float2* __restrict__ dst, const float2* __restrict__ tw, const float2* __restrict__ rowph,
+                                           int Ny, int NyB, int Nyr, int j, int nrows)
+{
+    constexpr int H = NK / 2, HL = NL / 2;
+    float2 v0, sv[H > 0 ? H : 1], dv[H > 0 ? H : 1];
+    {
+        float2 cp[HL > 0 ? HL : 1];
+        const int jB = map_up_col(j, Ny, NyB);
+#pragma unroll
+        for (int l = 0; l < HL; ++l) cp[l] = phase_tw(tw, jB, l + 1, NyB);
+        float2 v[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            v[k] = make_float2(c[k * NL + HL], 0.f);
+#pragma unroll
+            for (int l = 0; l < HL; ++l) {
+                const float cpl = c[k * NL + HL + 1 + l], cmi = c[k * NL + HL - 1 - l];
+                v[k].x = fmaf(cpl + cmi, cp[l].x, v[k].x);
+                v[k].y = fmaf(cpl - cmi, cp[l].y, v[k].y);
+            }
+        }
+        v0 = v[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { sv[k] = v[H + 1 + k] + v[H - 1 - k]; dv[k] = v[H + 1 + k] - v[H - 1 - k]; }
+    }
+    for (int i = 0; i < nrows; ++i) {
+        float2 acc = v0;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const float2 rp = rowph[i * H + k];
+            acc.x = fmaf(rp.x, sv[k].x, acc.x); acc.x = fmaf(-rp.y, dv[k].y, acc.x);
+            acc.y = fmaf(rp.y, dv[k].x, acc.y); acc.y = fmaf(rp.x, sv[k].y, acc.y);
+        }
+        dst[(long)i * Nyr] = acc;
+    }
+}
+
+// G' = F'.C' / (dM dD) of one pair (the collapsed operator the post-update MSE needs, fft_backproplib.cu:1460-1463) is the spectrum
+// of the (2NK-1)^2-tap kernel  gsp[d'][d] = scale * sum_m f'[d'][m] (*) c'[m][d]  (weight_kernels.hip).  Here a workgroup that
+// transforms the planes (d', d0 .. d0+np) forms their taps itself, from the pair's taps READ THROUGH the pending update (TapUpd):
+// f'[d'][.] and c'[.][d0..] staged in LDS, thread <-> (plane, output row tx, slice of m) owns the T outputs of that row (per (m, k)
+// one row of f' and one of c' feed NK*NK FMAs in registers), slices summed in slice order.  taps_s [np][T*T].
+template <int NK>
+__device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd, int dp, int d0, int np, float* __restrict__ taps_s, float* __restrict__ work)
+{
+    constexpr int T = 2 * NK - 1, KK = NK * NK;
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int dM = gs.dM, dD = gs.dD;
+    float* fs = work;                                    // [dM][KK]
+    float* cs = fs + dM * KK;                            // [np][dM][KK]
+    float* part = cs + np * dM * KK;                     // [slices][np*T][T]
+    const long nk = (long)dM * dD * KK;                  // f follows c (c|f, dck|dfk, Dc|Df: each pair contiguous)
+    auto tap = [&](long idx, float w, float gq, float dq) { return upd.g ? w - clip_step(gq * upd.gscale, dq, upd.del, upd.alpha) : w; };
+    const int nf = dM * KK, nc = np * dM * KK;
+    for (int t0 = 0; t0 < nf + nc; t0 += 4 * NT) {       // batches of independent loads (one round trip per batch)
+        float w[4], gq[4], dq[4];
+        long idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + u * NT + tid, nf + nc - 1);
+            if (t < nf) idx[u] = nk + (long)dp * dM * KK + t;
+            else {
+                const int t2 = t - nf;
+                const int m = t2 / (np * KK), r = t2 - m * (np * KK);
+                idx[u] = ((long)m * dD + d0) * KK + r;
+            }
+            w[u] = gs.c[idx[u]];
+            if (upd.g) { gq[u] = upd.g[idx[u]]; dq[u] = upd.D[idx[u]]; } else { gq[u] = 0.f; dq[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * NT + tid;
+            if (t >= nf + nc) continue;
+            const float v = tap(idx[u], w[u], gq[u], dq[u]);
+            if (t < nf) fs[t] = v;
+            else {
+                const int t2 = t - nf;
+                const int m = t2 / (np * KK), r = t2 - m * (np * KK);
+                const int i = r / KK, rr = r - i * KK;
+                cs[(i * dM + m) * KK + rr] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int items = np * T;
+    int nsl = NT / items;
+    if (nsl > dM) nsl = dM;
+    if (nsl < 1) nsl = 1;
+    for (int t = tid; t < items * nsl; t += NT) {
+        const int sl = t / items, it = t - sl * items;
+        const int i = it / T, tx = it - i * T;
+        float acc[T];
+#pragma unroll
+        for (int y = 0; y < T; ++y) acc[y] = 0.f;
+        for (int m = sl; m < dM; m += nsl) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int k2 = tx - k;
+                const bool ok = k2 >= 0 && k2 < NK;
+                const float* fr = fs + m * KK + k * NK;
+                const float* cr = cs + (i * dM + m) * KK + (ok ? k2 : 0) * NK;
+                float f5[NK], c5[NK];
+#pragma unroll
+                for (int l = 0; l < NK; ++l) { f5[l] = ok ? fr[l] : 0.f; c5[l] = cr[l]; }
+#pragma unroll
+                for (int l = 0; l < NK; ++l)
+#pragma unroll
+                    for (int l2 = 0; l2 < NK; ++l2) acc[l + l2] = fmaf(f5[l], c5[l2], acc[l + l2]);
+            }
+        }
+#pragma unroll
+        for (int y = 0; y < T; ++y) part[(sl * items + it) * T + y] = acc[y];
+    }
+    __syncthreads();
+    for (int t = tid; t < items * T; t += NT) {
+        float a = part[t];
+        for (int sl = 1; sl < nsl; ++sl) a += part[sl * items * T + t];
+        taps_s[t] = a * gs.scale;                        // (t = (plane*T + tx)*T + ty: the [np][T*T] layout)
+    }
+}
+
 template <int NK, int NL>
 __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float2* __restrict__ K,
                                                     const float2* __restrict__ tw, long planes, int Nx, int Ny,
-                                                    int rows_per_chunk, int ppb, int bx, int by, float2* lds, const TapUpd& upd = TapUpd{})
+                                                    int rows_per_chunk, int ppb, int bx, int by, float2* lds, const TapUpd& upd = TapUpd{},
+                                                    int NxB = 0, int NyB = 0)
 {
+    if (NxB == 0) { NxB = Nx; NyB = Ny; }
     // The tap offsets are symmetric (kap = -H .. H, lam = -HL .. HL) and the phase of -kap is the conjugate of kap's, so a pair of
     // taps shares its phase:  c+ e + c- conj(e) = (c+ + c-) ex + i (c+ - c-) ey  (column factor, real taps: 2 FMAs per pair),
     // v+ p + v- conj(p) = (px sx - py dy) + i (py dx + px sy)  with s = v+ + v-, d = v+ - v-  (row sum: 4 FMAs per pair instead of 8,
     // one phase read instead of two).  s and d are formed once per thread: the column factor does not depend on the row.
-    constexpr int H = NK / 2, HL = NL / 2;
+    constexpr int H = NK / 2;
     static_assert(NK % 2 == 1 && NL % 2 == 1, "symmetric tap offsets");
     const int Nyr = Ny / 2 + 1;
     float2* rowph = lds;                                 // [rows_per_chunk][H]: offsets 1 .. H
     float* taps_s = reinterpret_cast<float*>(rowph + rows_per_chunk * H);      // [ppb][NK*NL]: the planes' taps, staged once per workgroup
     const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
-    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase(tw, i0 + t / H, t % H + 1, Nx, 1.f);
+    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, map_up_row(i0 + t / H, Nx, NxB), t % H + 1, NxB);
     {
         // (through the pending update when there is one -- uniform --: w - clip_step(g, D), TapUpd)
         const long e0 = (long)bx * ppb * (NK * NL);
@@ -77,38 +205,31 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
     const long plane = (long)bx * ppb + pl;
     if (pl >= ppb || plane >= planes) return;
-    float2 v0, sv[H > 0 ? H : 1], dv[H > 0 ? H : 1];
-    {
-        float2 cp[HL > 0 ? HL : 1];
-#pragma unroll
-        for (int l = 0; l < HL; ++l) cp[l] = phase(tw, j, l + 1, Ny, 1.f);
-        const float* c = taps_s + pl * (NK * NL);
-        float2 v[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            v[k] = make_float2(c[k * NL + HL], 0.f);
-#pragma unroll
-            for (int l = 0; l < HL; ++l) {
-                const float cpl = c[k * NL + HL + 1 + l], cmi = c[k * NL + HL - 1 - l];
-                v[k].x = fmaf(cpl + cmi, cp[l].x, v[k].x);
-                v[k].y = fmaf(cpl - cmi, cp[l].y, v[k].y);
-            }
-        }
-        v0 = v[H];
-#pragma unroll
-        for (int k = 0; k < H; ++k) { sv[k] = v[H + 1 + k] + v[H - 1 - k]; dv[k] = v[H + 1 + k] - v[H - 1 - k]; }
-    }
-    float2* dst = K + (plane * Nx + i0) * (long)Nyr + j;
-    for (int i = 0; i < nrows; ++i) {
-        float2 acc = v0;
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const float2 rp = rowph[i * H + k];
-            acc.x = fmaf(rp.x, sv[k].x, acc.x); acc.x = fmaf(-rp.y, dv[k].y, acc.x);
-            acc.y = fmaf(rp.y, dv[k].x, acc.y); acc.y = fmaf(rp.x, sv[k].y, acc.y);
-        }
-        dst[(long)i * Nyr] = acc;
-    }
+    kspec_rows<NK, NL>(taps_s + pl * (NK * NL), K + (plane * Nx + i0) * (long)Nyr + j, tw, rowph, Ny, NyB, Nyr, j, nrows);
+}
+
+// the G' form of kspec_body: workgroup = (d', tile of ppb d's) x row chunk; the taps come from gtaps_stage
+template <int NK>
+__device__ __forceinline__ void gspec_gbody(const GtapSrc& gs, float2* __restrict__ G, const float2* __restrict__ tw, int Nx, int Ny,
+                                            int rows_per_chunk, int ppb, int bx, int by, float2* lds, const TapUpd& upd)
+{
+    constexpr int T = 2 * NK - 1, TT = T * T, H = T / 2;
+    const int Nyr = Ny / 2 + 1;
+    float2* rowph = lds;                                                     // [rows_per_chunk][H]
+    float* taps_s = reinterpret_cast<float*>(rowph + rows_per_chunk * H);    // [ppb][TT]
+    float* work = taps_s + ppb * TT;
+    const int i0 = by * rows_per_chunk;
+    const int nrows = min(rows_per_chunk, Nx - i0);
+    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, i0 + t / H, t % H + 1, Nx);
+    const int tiles = (gs.dD + ppb - 1) / ppb;
+    const int dp = bx / tiles, d0 = (bx - dp * tiles) * ppb;
+    const int np = min(ppb, gs.dD - d0);
+    gtaps_stage<NK>(gs, upd, dp, d0, np, taps_s, work);
+    __syncthreads();
+    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    if (pl >= np) return;
+    const long plane = (long)dp * gs.dD + d0 + pl;
+    kspec_rows<T, T>(taps_s + pl * TT, G + (plane * Nx + i0) * (long)Nyr + j, tw, rowph, Ny, Ny, Nyr, j, nrows);
 }
 
 template <int NK, int NL>
@@ -146,8 +267,14 @@ __global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, c
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const int lin = blockIdx.x - g.start[p];
     const PrunedProb& q = g.q[p];
+    if constexpr (NK == NL && (NK == 3 || NK == 5)) {
+        if (g.gsrc[p].f) {                                // (uniform) a G' problem: the (2NK-1)^2 taps are formed in the workgroup
+            gspec_gbody<NK>(g.gsrc[p], static_cast<float2*>(q.dst), tw, q.Nx, q.Ny, g.rows[p], g.ppb[p], lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p]);
+            return;
+        }
+    }
     kspec_body<NK, NL>(static_cast<const float*>(q.src), static_cast<float2*>(q.dst), tw, q.planes, q.Nx, q.Ny, g.rows[p], g.ppb[p],
-                       lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p]);
+                       lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p], q.NxB, q.NyB);
 }
 
 // Thread <-> (plane, column j) over a chunk of RB rows:
@@ -494,15 +621,33 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); }
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
-        g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
         // <= 64 rows per workgroup for every problem (a launch-wide chunk count gave the big grids 128-row workgroups on half their
         // lanes: 23.7 us against 21.5 us at cfg3; 32 rows: 22.0, 16 rows: 24.9)
         const int chunks = (q.Nx + 63) / 64;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
+        if (g.gsrc[p].f) {
+            // G' problem (gspec_gbody): plane groups (d', tile of ppb d's); LDS = row phases | taps | f' | c' tile | slice partials
+            if (!(NK == NL && (NK == 3 || NK == 5))) return hipErrorInvalidValue;
+            constexpr int T = 2 * NK - 1;
+            const GtapSrc& gs = g.gsrc[p];
+            auto need = [&](int ppb) { return sizeof(float2) * (size_t)g.rows[p] * (T / 2) + sizeof(float) * ((size_t)ppb * T * T + (size_t)gs.dM * NK * NK * (1 + ppb) + (size_t)320 * T); };
+            int ppb = std::min(g.ppb[p], gs.dD);
+            while (ppb > 1 && need(ppb) > 64 * 1024) --ppb;
+            if (need(ppb) > 150 * 1024) return hipErrorInvalidValue;
+            g.ppb[p] = ppb;
+            g.pblocks[p] = gs.dD * ((gs.dD + ppb - 1) / ppb);
+            lds = std::max(lds, need(ppb));
+        } else {
+            g.pblocks[p] = (int)((q.planes + g.ppb[p] - 1) / g.ppb[p]);
+            lds = std::max(lds, kspec_lds(g.rows[p], NK, g.ppb[p]));
+        }
         g.start[p] = total; total += g.pblocks[p] * chunks;
-        lds = std::max(lds, kspec_lds(g.rows[p], NK, g.ppb[p]));
     }
     g.start[g.n] = total;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_group_kernel<NK, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     int threads = 256;                                    // one thread per (plane in group, column)
     for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
     if (threads > 320) return hipErrorInvalidValue;

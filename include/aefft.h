@@ -71,7 +71,8 @@ enum {
     AEFFT_F_POISON = 1 << 15,     /* NaN-fill every allocation (uninitialised reads show up in the tests) */
     AEFFT_F_NOOPFORM = 1 << 16,   /* training step per frame (batch contractions) instead of the operator form */
     AEFFT_F_NOCHAIN = 1 << 17,    /* operator form: the network on the basis frames layer by layer instead of one fused launch */
-    AEFFT_F_NOFUSEUPD = 1 << 18   /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
+    AEFFT_F_NOFUSEUPD = 1 << 18,  /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
+    AEFFT_F_NOAHEAD = 1 << 19     /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);
