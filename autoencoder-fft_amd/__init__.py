@@ -22,6 +22,7 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 FLAGS = {n: 1 << i for i, n in enumerate(
     ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
      "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD"])}
+FLAGS.update({"X28": 1 << 28, "X29": 1 << 29, "X30": 1 << 30})
 
 
 class AefftError(RuntimeError):

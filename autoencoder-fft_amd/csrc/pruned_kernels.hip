@@ -66,6 +66,8 @@ __device__ __forceinline__ void kspec_rows(const float* __restrict__ c, float2* 
 #pragma unroll
         for (int k = 0; k < H; ++k) { sv[k] = v[H + 1 + k] + v[H - 1 - k]; dv[k] = v[H + 1 + k] - v[H - 1 - k]; }
     }
+    // (4 rows per trip: the phase reads of the next rows are in flight while a row's FMAs issue -- a rolled loop is one LDS round trip per row)
+#pragma unroll 4
     for (int i = 0; i < nrows; ++i) {
         float2 acc = v0;
 #pragma unroll
@@ -89,38 +91,41 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
     constexpr int T = 2 * NK - 1, KK = NK * NK;
     const int NT = blockDim.x, tid = threadIdx.x;
     const int dM = gs.dM, dD = gs.dD;
+    // cs: plane stride padded to an odd number of floats (planes dM*KK apart share a bank: the tiles' rows would collide np-fold)
+    const int CS = dM * KK + ((dM * KK) & 1 ? 0 : 1);
     float* fs = work;                                    // [dM][KK]
-    float* cs = fs + dM * KK;                            // [np][dM][KK]
-    float* part = cs + np * dM * KK;                     // [slices][np*T][T]
-    const long nk = (long)dM * dD * KK;                  // f follows c (c|f, dck|dfk, Dc|Df: each pair contiguous)
-    auto tap = [&](long idx, float w, float gq, float dq) { return upd.g ? w - clip_step(gq * upd.gscale, dq, upd.del, upd.alpha) : w; };
+    float* cs = fs + dM * KK;                            // [np][CS]: c'[m][d0+i] at i*CS + m*KK
+    float* part = work;                                  // [slices][np*T][T]: takes the place of fs | cs once every slice has its sums in registers
+    const unsigned nk = (unsigned)(dM * dD * KK);        // f follows c (c|f, dck|dfk, Dc|Df: each pair contiguous); element offsets fit 32 bits
     const int nf = dM * KK, nc = np * dM * KK;
-    for (int t0 = 0; t0 < nf + nc; t0 += 4 * NT) {       // batches of independent loads (one round trip per batch)
-        float w[4], gq[4], dq[4];
-        long idx[4];
+    constexpr int U = 16;                                // loads per array and batch (registers: the launch's other workgroups pay for every one)
+    for (int t0 = 0; t0 < nf + nc; t0 += U * NT) {
+        float w[U], gq[U], dq[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u * NT >= nf + nc) break;                       // uniform: whole load instructions are skipped
             const int t = min(t0 + u * NT + tid, nf + nc - 1);
-            if (t < nf) idx[u] = nk + (long)dp * dM * KK + t;
+            unsigned idx;
+            if (t < nf) idx = nk + (unsigned)(dp * dM * KK + t);
             else {
                 const int t2 = t - nf;
                 const int m = t2 / (np * KK), r = t2 - m * (np * KK);
-                idx[u] = ((long)m * dD + d0) * KK + r;
+                idx = (unsigned)((m * dD + d0) * KK + r);
             }
-            w[u] = gs.c[idx[u]];
-            if (upd.g) { gq[u] = upd.g[idx[u]]; dq[u] = upd.D[idx[u]]; } else { gq[u] = 0.f; dq[u] = 0.f; }
+            w[u] = gs.c[idx];
+            if (upd.g) { gq[u] = upd.g[idx]; dq[u] = upd.D[idx]; } else { gq[u] = 0.f; dq[u] = 0.f; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int t = t0 + u * NT + tid;
             if (t >= nf + nc) continue;
-            const float v = tap(idx[u], w[u], gq[u], dq[u]);
+            const float v = upd.g ? w[u] - clip_step(gq[u] * upd.gscale, dq[u], upd.del, upd.alpha) : w[u];
             if (t < nf) fs[t] = v;
             else {
                 const int t2 = t - nf;
                 const int m = t2 / (np * KK), r = t2 - m * (np * KK);
                 const int i = r / KK, rr = r - i * KK;
-                cs[(i * dM + m) * KK + rr] = v;
+                cs[i * CS + m * KK + rr] = v;
             }
         }
     }
@@ -129,19 +134,23 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
     int nsl = NT / items;
     if (nsl > dM) nsl = dM;
     if (nsl < 1) nsl = 1;
-    for (int t = tid; t < items * nsl; t += NT) {
-        const int sl = t / items, it = t - sl * items;
-        const int i = it / T, tx = it - i * T;
-        float acc[T];
+    // (items * nsl <= NT: one (plane, row, slice) per thread)
+    const int t = tid;
+    const bool work_thr = t < items * nsl;
+    const int sl = t / items, it = t - sl * items;
+    float acc[T];
 #pragma unroll
-        for (int y = 0; y < T; ++y) acc[y] = 0.f;
+    for (int y = 0; y < T; ++y) acc[y] = 0.f;
+    if (work_thr) {
+        const int i = it / T, tx = it - i * T;
+#pragma unroll 2
         for (int m = sl; m < dM; m += nsl) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int k2 = tx - k;
                 const bool ok = k2 >= 0 && k2 < NK;
                 const float* fr = fs + m * KK + k * NK;
-                const float* cr = cs + (i * dM + m) * KK + (ok ? k2 : 0) * NK;
+                const float* cr = cs + i * CS + m * KK + (ok ? k2 : 0) * NK;
                 float f5[NK], c5[NK];
 #pragma unroll
                 for (int l = 0; l < NK; ++l) { f5[l] = ok ? fr[l] : 0.f; c5[l] = cr[l]; }
@@ -151,14 +160,17 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
                     for (int l2 = 0; l2 < NK; ++l2) acc[l + l2] = fmaf(f5[l], c5[l2], acc[l + l2]);
             }
         }
+    }
+    __syncthreads();                                     // every read of fs | cs is done
+    if (work_thr) {
 #pragma unroll
         for (int y = 0; y < T; ++y) part[(sl * items + it) * T + y] = acc[y];
     }
     __syncthreads();
-    for (int t = tid; t < items * T; t += NT) {
-        float a = part[t];
-        for (int sl = 1; sl < nsl; ++sl) a += part[sl * items * T + t];
-        taps_s[t] = a * gs.scale;                        // (t = (plane*T + tx)*T + ty: the [np][T*T] layout)
+    for (int t2 = tid; t2 < items * T; t2 += NT) {
+        float a = part[t2];
+        for (int s2 = 1; s2 < nsl; ++s2) a += part[s2 * items * T + t2];
+        taps_s[t2] = a * gs.scale;                       // (t2 = (plane*T + tx)*T + ty: the [np][T*T] layout)
     }
 }
 
@@ -630,9 +642,12 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
             if (!(NK == NL && (NK == 3 || NK == 5))) return hipErrorInvalidValue;
             constexpr int T = 2 * NK - 1;
             const GtapSrc& gs = g.gsrc[p];
-            auto need = [&](int ppb) { return sizeof(float2) * (size_t)g.rows[p] * (T / 2) + sizeof(float) * ((size_t)ppb * T * T + (size_t)gs.dM * NK * NK * (1 + ppb) + (size_t)320 * T); };
-            int ppb = std::min(g.ppb[p], gs.dD);
-            while (ppb > 1 && need(ppb) > 64 * 1024) --ppb;
+            auto need = [&](int ppb) { return sizeof(float2) * (size_t)g.rows[p] * (T / 2) + sizeof(float) * ((size_t)ppb * T * T + std::max((size_t)(gs.dM * NK * NK + 1) * (1 + ppb), (size_t)320 * T)); };
+            // (a launch's dynamic LDS size applies to EVERY workgroup: the tile shrinks until it fits beside what the ordinary problems need)
+            // ... and so that (planes x output rows x slices of m) fill the workgroup with about two m's per slice: the tap products are
+            // a dependent stage in front of the transform, more and smaller tiles shorten it (5 planes: 24.8 us for the launch at cfg3, 2: see DESIGN.md)
+            int ppb = std::min(std::min(g.ppb[p], gs.dD), std::max(1, (2 * 320) / (T * gs.dM)));
+            while (ppb > 1 && need(ppb) > 26 * 1024) --ppb;
             if (need(ppb) > 150 * 1024) return hipErrorInvalidValue;
             g.ppb[p] = ppb;
             g.pblocks[p] = gs.dD * ((gs.dD + ppb - 1) / ppb);
