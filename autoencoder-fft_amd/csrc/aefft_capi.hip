@@ -950,6 +950,7 @@ struct aefft_net {
     bool ev_mid_valid = false;
     bool ev_end_valid[2] = {false, false};
     unsigned long step_no = 0;
+    float2* recon_exp = nullptr;  // [B][D][PO] per-frame output spectra of the reconstruction when they are written out (large supports, launch_recon)
     unsigned ox_done = 0;         // bit l: the forward already launched pair l's support term S += sum_b Oc X^H
     bool xx_done = false;         // the forward already launched S = -sum_b X X^H (grouped with the innermost decoder conv)
     bool recon_pending = false;   // the reconstruction's inverse FFT is still running on aux[0]
@@ -1317,8 +1318,21 @@ static int launch_recon(aefft_net* n, float* recon_d, int wsid)
     const float2* src = ov.O;
     const int nxo = ov.nxo, nyo = ov.nyo;
     if (op_mode(n)) {
-        // operator form: O_0,b = O^_0 [x_b; 1] is evaluated inside the column pass of the inverse transform (no stored planes)
         static_assert(OPIN_COLS == OPC, "operator width");
+        const long PO = bins(nxo, nyo);
+        if ((double)n->B * q.dD * PO * 8.0 > 16e6) {
+            // large supports (no pooling: the decoder output lives on the whole grid): the per-frame spectra O_0,b = O^_0 [x_b; 1] are
+            // written out once by a coalesced pass (7 plane-ordered loads per output) and the inverse transform reads them back.  Evaluated
+            // inside the column pass instead, the same 7 loads are strided 128-byte pieces: 1.1 ms against 0.2 ms at cfg3-P1.
+            if (!n->recon_exp) RET_IF(net_alloc_t(n, &n->recon_exp, (size_t)n->B * q.dD * PO));
+            {
+                Bracket br(ctx, KID_OPFORM, ((double)OPC * q.dD * PO + (double)n->B * q.dD * PO + (double)n->B * q.dD * q.P) * 8.0);
+                hipError_t e = launch_recon_expand(src, n->Xf, n->recon_exp, n->B, q.dD, q.Nx, q.Ny, nxo, nyo, ctx->cur);
+                if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "recon_expand", e);
+            }
+            return do_c2r(ctx, n->recon_exp, recon_d, (long)n->B * q.dD, nxo, nyo, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid);
+        }
+        // small supports: O_0,b = O^_0 [x_b; 1] is evaluated inside the column pass of the inverse transform (no stored planes)
         const OpIn op{src, n->Xf, q.dD, q.Nx, q.Ny};
         return do_c2r(ctx, nullptr, recon_d, (long)n->B * q.dD, nxo, nyo, n->Nx, n->Ny, 1.0f / ((float)n->Nx * (float)n->Ny), wsid, &op);
     }
@@ -2041,6 +2055,41 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         q.spectra_valid = true;
     }
     if (op_mode(n) && n->Wp) RET_IF(ensure_packed(n));     // the next step's chain reads the bin-major copy of the NEW weights
+    bool g_taps = false;                                   // G' of EVERY pair at hand (operator form without the chain launch, HBM-sized spectra)
+    if (op_mode(n) && !gp_route) {
+        // HBM-sized kernel spectra (no pooling): the post-update MSE would read all 2*dM*dD planes of C'|F' back (6 GB at cfg3-P1).  G' =
+        // F'.C'/(dM dD) as the spectrum of the (2Nk-1)^2-tap kernel f' (*) c' (weight_kernels.hip) is dD*dD planes written and read once.
+        double cf_bytes = 0;
+        for (int l = 0; l < n->L; ++l) cf_bytes += 2.0 * n->pr[l].dM * n->pr[l].dD * n->pr[l].P * 8.0;
+        bool ok = (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && !fused_upd /* the taps are stored */ && !flag(AEFFT_F_NOQPATH) && n->L <= 8 && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
+        for (int l = 0; l < n->L && ok; ++l) { const Pair& q = n->pr[l]; ok = q.Q && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nk && (double)q.dD * q.dD * q.P * 8.0 < 4294967296.0; }
+        if (ok) {
+            GspGroup gg{};
+            PrunedGroup pg{};
+            const int T = 2 * n->pr[0].Nk - 1;
+            double gbytes = 0, kbytes = 0;
+            for (int l = 0; l < n->L; ++l) {
+                Pair& q = n->pr[l];
+                gg.q[l] = GspProb{q.c, q.f, q.Q, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};     // Q is dead after the weight gradients: reused for the taps
+                pg.q[l] = PrunedProb{q.Q, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
+                gbytes += (2.0 * q.dM * q.dD * q.Nk * q.Nl + (double)q.dD * q.dD * T * T) * 4.0;
+                kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
+            }
+            gg.n = pg.n = n->L;
+            hipError_t e;
+            {
+                Bracket br(ctx, KID_WGRAD, gbytes);
+                e = launch_gspatial_group(gg, n->pr[0].Nk, ctx->cur);
+            }
+            if (e == hipSuccess) {
+                Bracket br(ctx, KID_KSPEC, kbytes);
+                e = launch_kspec_group_taps(pg, ctx->tw, T, ctx->cur);
+            }
+            if (e == hipSuccess) g_taps = true;
+            else if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G'(taps)", e);
+            else (void)hipGetLastError();
+        }
+    }
     if (op_mode(n)) {
         // post-update MSE (fft_backproplib.cu:1460-1463) in operator form: R = A - F'(C' A / dM + b^) / dD - p^ per bin, then
         // sum_a R[a] M^ R[a]^H; the updated spectra (or their product G') are read once, nothing is stored (opform_kernels.hip)
@@ -2056,6 +2105,10 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             o.dD = q.dD; o.dM = q.dM; o.Nx = q.Nx; o.Ny = q.Ny; o.P = q.P; o.scale = scale;
             if (gp_route && l + 1 < n->L) {
                 o.G = q.G; o.Fdc = n->Wp + n->pack.seg[2 * n->L - 1 - l].off; o.fdc_stride = 1;      // (F' at the DC bin: record 0 of the bin-major copy)
+                bytes += ((double)q.dD * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
+            } else if (g_taps && !(l == n->L - 1 && inner_packed)) {
+                RET_IF(ensure_spectra(n, q));
+                o.G = q.G; o.Fdc = q.F; o.fdc_stride = q.P;                                            // (the planar F', DC bin)
                 bytes += ((double)q.dD * q.dD + (double)OPC * q.dD + (double)OPC * OPC) * q.P * 8.0;
             } else {
                 if (!(l == n->L - 1 && inner_packed)) RET_IF(ensure_spectra(n, q));

@@ -245,14 +245,21 @@ __global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
         }
     }
 }
-static int msgrad_bt(int dD) { return dD <= 4 ? 64 : (dD <= 8 ? 32 : (dD <= 16 ? 16 : 8)); }
+// bins per workgroup: 256 threads = bins x row threads.  Cache-sized grids: as many row threads as rows (shortest dependent path per
+// workgroup); HBM-sized grids (no pooling): at least 16 bins, so that the plane accesses are whole 128-byte lines, while the tiles fit
+static int msgrad_bt(int dD, long P)
+{
+    int bt = dD <= 4 ? 64 : (dD <= 8 ? 32 : (dD <= 16 ? 16 : 8));
+    if (P >= 32768 && bt < 16 && (size_t)2 * OPC * dD * 16 * sizeof(float2) <= 64 * 1024) bt = 16;
+    return bt;
+}
 hipError_t launch_msgrad_group(SgradGroup& g, hipStream_t st)
 {
     if (g.n < 1 || g.n > 8 || !g.Xf || g.B < 1 || g.D0 < 1 || g.D0 > OPC - 1 || g.P0 >= (1L << 28)) return hipErrorInvalidValue;
     long total = 0;
     size_t lds = 0;
     for (int i = g.n - 1; i >= 0; --i) {                               // (start[] is DEscending in i: see the kernel's lookup)
-        const int bt = msgrad_bt(g.q[i].dD);
+        const int bt = msgrad_bt(g.q[i].dD, g.q[i].P);
         g.bt[i] = bt;
         g.start[i] = (int)total;
         total += (g.q[i].P + bt - 1) / bt;
@@ -771,7 +778,7 @@ static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t*
         if (pk) need = OPMSE_PACKED_LDS;
         else if (q.G) {                                                  // opmse_gbody
             if ((double)q.dD * q.dD * q.P * 8.0 >= 4294967296.0) return hipErrorInvalidValue;
-            bt = q.dD <= 4 ? 64 : (q.dD <= 8 ? 32 : (q.dD <= 16 ? 16 : 8));
+            bt = msgrad_bt(q.dD, q.P);
             need = sizeof(float2) * ((size_t)OPC * q.dD * bt + (size_t)OPC * OPC * bt) + 64;
         } else if (q.dM == 8 && q.dD <= 4 && !flag(AEFFT_F_NOFAST)) { bt = 32; need = (size_t)OPC * (4 + 8) * 32 * sizeof(float2) + 64; }     // opmse_small_body (bt == 32 selects it)
         if (i == g.n - 1 && !pk) g.Wp = nullptr;
@@ -869,17 +876,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
     const long s0 = (long)(bx - g.tile_start[j]) * CH_BT;
     const long s = min(s0 + bl, lj.P - 1);
     const bool ok = s0 + bl < lj.P;
-    long sb[8];
-    sb[j] = s;
-#pragma unroll
-    for (int i = 7; i > 0; --i) if (i <= j) sb[i - 1] = map_up(sb[i], g.lv[i].Nx, g.lv[i].Ny, g.lv[i - 1].Nx, g.lv[i - 1].Ny);
     // V tiles in LDS: [row][col][bin], ping-pong halves of Wl
     float2* Vt[2] = {Wl, Wl + g.vt_elems};
     for (int i = tid; i < OPC * OPC * CH_BT; i += 256) { const int b2 = i % CH_BT, c = (i / CH_BT) % OPC, k = i / (CH_BT * OPC); Vt[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); (void)b2; }
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        if (i > j) break;
-        const ChainLevel w = g.lv[i - 1];
+    // (a ROLLED loop over the levels: unrolled, the seven copies of the stage body cost 121 registers -- half the occupancy of the
+    // launch, which hosts the per-bin items and the MSE as well; the level's descriptor is a uniform, scalar-loaded index)
+#pragma unroll 1
+    for (int i = 1; i <= j; ++i) {
+        const ChainLevel& w = g.lv[i - 1];
+        // the tile's bin on grid i and on grid i-1 (pool_fft's index map composes to the same form)
+        const long sbi = i == j ? s : map_up(s, lj.Nx, lj.Ny, g.lv[i].Nx, g.lv[i].Ny);
+        const long sbm = map_up(s, lj.Nx, lj.Ny, w.Nx, w.Ny);
         const int R = w.dM, K = w.dD;
         const float scale = 1.0f / (float)w.dM, NN = (float)w.Nx * (float)w.Ny;
         const float2* Vin = Vt[(i - 1) & 1];
@@ -891,7 +898,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
             for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
             // (the pair's planar spectrum, or its compact copy Cc sampled where grid i lands: then bin sb[i] of planes of lv[i].P bins)
             const long pst = w.Cc ? g.lv[i].P : w.P;
-            const float2* Wp = (w.Cc ? w.Cc + sb[i] : w.C + sb[i - 1]) + (long)r * K * pst;
+            const float2* Wp = (w.Cc ? w.Cc + sbi : w.C + sbm) + (long)r * K * pst;
             auto grp = [&](int k0, auto NU) {
                 constexpr int U = decltype(NU)::value;
                 float2 wv[U];
@@ -910,7 +917,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
             if (k0 < K) grp(k0, std::integral_constant<int, 1>{});
 #pragma unroll
             for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
-            if (sb[i] == 0) acc[OPC - 1].x += w.b[r] * NN;
+            if (sbi == 0) acc[OPC - 1].x += w.b[r] * NN;
 #pragma unroll
             for (int c = 0; c < OPC; ++c) {
                 Vout[(r * OPC + c) * CH_BT + bl] = acc[c];
@@ -964,7 +971,7 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
 // the OTHER set of operator buffers; the MSE reads the operators of the step that is ending.  Nothing in the launch depends on
 // anything else in it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
+__global__ __launch_bounds__(256, 4) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
 {
     extern __shared__ float2 sh[];
     if ((int)blockIdx.x < nchain) { chain_body(ch, blockIdx.x, sh); return; }

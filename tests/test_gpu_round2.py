@@ -304,3 +304,33 @@ def test_operator_form_stays_on_the_per_frame_numbers_after_training(ctx, flags)
         assert relerr(g_op[off:off + n], g_pf[off:off + n]) < 5e-5
         off += n
     assert np.allclose(m_op, m_pf, rtol=1e-4)
+
+
+def test_large_support_reconstruction_and_gprime_route_equal_the_per_frame_form(ctx, flags):
+    """No pooling, enough frames that the reconstruction's per-frame spectra are written out by the expansion pass (launch_recon's
+    large-support route) and, with GTAPS, the post-update MSE through G' = F'.C' formed from the taps (the route cfg3-P1 takes by
+    size): reconstruction, gradients, weights and MSE against the per-frame form of the same library."""
+    rng = np.random.default_rng(909)
+    D, N, maps, Nk, s, B = 3, 256, [4, 6], 5, 1, 24
+    ws = _weights(rng, D, maps, Nk)
+    frames = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    res = []
+    for path in (["NOOPFORM"], ["GTAPS"]):
+        flags(*path)
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        recon, mse = ctx.empty(B, D, N, N), ctx.empty(len(maps))
+        net.step_grad(frames, recon)
+        g = host(net.grad_buffer()).copy()
+        net.step_apply(0.2, 0, 0, 1.0, mse)
+        res.append((g, [net.get_pair(l) for l in range(len(maps))], host(recon).copy(), host(mse).copy()))
+        net.close()
+    (g0, w0, r0, m0), (g1, w1, r1, m1) = res
+    assert relerr(r1, r0) < 2e-5
+    off = 0
+    for l, (c, b, f, p) in enumerate(ws):
+        n = 2 * c.size + b.size + p.size
+        assert relerr(g1[off:off + n], g0[off:off + n]) < 5e-5, l
+        off += n
+    assert np.allclose(m1, m0, rtol=1e-4), (m0, m1)
