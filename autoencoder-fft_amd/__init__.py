@@ -22,7 +22,6 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 FLAGS = {n: 1 << i for i, n in enumerate(
     ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
      "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD"])}
-FLAGS.update({"X28": 1 << 28, "X29": 1 << 29, "X30": 1 << 30})
 
 
 class AefftError(RuntimeError):
@@ -79,6 +78,7 @@ SIGNATURES = {
     "aefft_net_step_grad": (_i, [_vp, _fp, _fp]),
     "aefft_net_set_input_ready": (_i, [_vp, _i]),
     "aefft_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "aefft_net_step_form": (_i, [_vp]),
     "aefft_net_step_apply": (_i, [_vp, _f, _i, _i, _f, _fp]),
     "aefft_net_reset_momentum": (_i, [_vp]),
     "aefft_prof_enable": (_i, [_vp, _i]),
@@ -435,6 +435,10 @@ class Net:
             holder = type("_Raw", (), {"__cuda_array_interface__": iface})()
             self._gradview = (p.value, t.as_tensor(holder, device=f"cuda:{self.ctx.device}"))
         return self._gradview[1]
+
+    def step_form(self):
+        """which form the next training step runs in: "per_frame", "operator" or "operator_chain" (aefft_net_step_form)"""
+        return ("per_frame", "operator", "operator_chain")[self.L.aefft_net_step_form(self.h)]
 
     def step_apply(self, del0, maxdiff=0, sym=0, grad_scale=1.0, mse=None):
         self.ctx.check(self.L.aefft_net_step_apply(self.h, del0, maxdiff, sym, grad_scale, _ptr(mse)))

@@ -110,6 +110,11 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
     {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}};
+// The switches named by AEFFT_FLAGS stay on for the life of the process: aefft_ctx_set_flags ORs its argument onto them (a test fixture
+// that restores "no flags" does not clear an AEFFT_FLAGS=POISON run).  A name the library does not know is an error, not a silent
+// default run: the first aefft_ctx_create fails with AEFFT_EINVAL and says which.
+static unsigned env_flags = 0;
+static std::string env_flags_error;
 static void flags_from_env_once()
 {
     static bool done = false;
@@ -123,11 +128,14 @@ static void flags_from_env_once()
         size_t j = s.find(',', i);
         if (j == std::string::npos) j = s.size();
         const std::string w = s.substr(i, j - i);
-        for (const auto& f : flag_names) if (w == f.name) dev_flags |= f.bit;
+        bool known = w.empty();
+        for (const auto& f : flag_names) if (w == f.name) { env_flags |= f.bit; known = true; }
+        if (!known) env_flags_error += (env_flags_error.empty() ? "" : ",") + w;
         i = j + 1;
     }
+    dev_flags = env_flags;
 }
-extern "C" int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags) { if (!ctx) return AEFFT_EINVAL; dev_flags = flags; return AEFFT_OK; }
+extern "C" int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags) { if (!ctx) return AEFFT_EINVAL; dev_flags = env_flags | flags; return AEFFT_OK; }
 extern "C" unsigned aefft_ctx_get_flags(const aefft_ctx*) { return dev_flags; }
 
 extern "C" const char* aefft_version(void) { return "aefft 0.2 (gfx950)"; }
@@ -137,6 +145,7 @@ extern "C" int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, i
     if (!out) return AEFFT_EINVAL;
     *out = nullptr;
     flags_from_env_once();
+    if (!env_flags_error.empty()) { fprintf(stderr, "aefft: unknown name(s) in AEFFT_FLAGS: %s\n", env_flags_error.c_str()); return AEFFT_EINVAL; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AEFFT_EHIP;
     aefft_ctx* ctx = new aefft_ctx();
@@ -1207,7 +1216,7 @@ static int build_chain_items(aefft_net* n)
     if (!dims_ok || n->pr[L - 1].P > 16384) return AEFFT_OK;
     // the bin-major copy for the coarsest-grid items: C_0 .. C_{L-1}, F_{L-1} .. F_0 in chain order, segments padded to even sizes
     bool pk = n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5) && 2 * L <= 16;
-    for (const Pair& q : n->pr) pk = pk && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nk && (((q.dM * q.dD + 1) & ~1) <= 6144);
+    for (const Pair& q : n->pr) pk = pk && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nk && (((q.dM * q.dD + 1) & ~1) <= CH_VMAX * CH_VMAX);      // (matrices are read from the record in place: only the row counts are bounded)
     if (pk) {
         PackArgs& pa = n->pack;
         int off = 0, ns = 0;
@@ -1250,6 +1259,34 @@ static int cc_problems(aefft_net* n, PrunedGroup& pg, int first, double* bytes)
     return k;
 }
 
+// G'_l = F_l.C_l / (dM dD) [dD][dD][P] of the STORED weights of every pair, into Pair::G: the spectrum of the (2Nk-1)^2-tap kernel f (*) c, taps
+// formed inside the transforming workgroups (gspec_gbody).  false: shapes not served.
+static int gprime_from_taps(aefft_net* n, bool* done)
+{
+    *done = false;
+    aefft_ctx* ctx = n->ctx;
+    if (n->L > 8 || n->pr[0].Nk != n->pr[0].Nl || (n->pr[0].Nk != 3 && n->pr[0].Nk != 5)) return AEFFT_OK;
+    PrunedGroup pg{};
+    double bytes = 0;
+    for (int l = 0; l < n->L; ++l) {
+        Pair& q = n->pr[l];
+        if (q.Nk != n->pr[0].Nk || q.Nl != n->pr[0].Nk || !pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny) || (double)q.dD * q.dD * q.P * 8.0 >= 4294967296.0) return AEFFT_OK;
+        pg.q[l] = PrunedProb{nullptr, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f, 0, 0};
+        pg.gsrc[l] = GtapSrc{q.c, q.f, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};
+        bytes += (double)q.dD * q.dD * q.P * 8.0 + 2.0 * q.dM * q.dD * q.Nk * q.Nl * 4.0;
+    }
+    pg.n = n->L;
+    hipError_t e;
+    {
+        Bracket br(ctx, KID_KSPEC, bytes);
+        e = launch_kspec_group(pg, ctx->tw, n->pr[0].Nk, n->pr[0].Nl, ctx->cur, nullptr, nullptr);
+    }
+    if (e == hipSuccess) { *done = true; return AEFFT_OK; }
+    if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G'(taps)", e);
+    (void)hipGetLastError();
+    return AEFFT_OK;
+}
+
 // the bin-major record Wp (and the compact Cc planes) of the CURRENT weights
 static int ensure_packed(aefft_net* n)
 {
@@ -1283,8 +1320,12 @@ static bool op_eligible(const aefft_net* n)
     const Pair& q0 = n->pr[0];
     if (q0.Nk != q0.Nl || (q0.Nk != 3 && q0.Nk != 5)) return false;
     for (const Pair& q : n->pr) if (q.Nk != q0.Nk || q.Nl != q0.Nl || !q.Q || !pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny)) return false;
+    // channel counts the operator-form kernels' LDS tiles take (msgrad_kernel: 2*OPC*dD*8 complex; opmse: OPC*(dD+dM)*4 complex): a
+    // launch declined in the middle of step_apply would leave a fused update half applied, so the step form is decided here
+    for (const Pair& q : n->pr) if (q.dD > 256 || q.dM > 512 || q.dD + q.dM > 1024) return false;
     return true;
 }
+static bool chain_switches_ok();
 
 // operator form: where pair l's operators of the step in progress are (A_l [OPC][dD][P], O^_l [OPC][dD][PO] on the grid nxo x nyo)
 struct OpView { const float2 *A, *O; int nxo, nyo; long PO; };
@@ -2061,34 +2102,8 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         // F'.C'/(dM dD) as the spectrum of the (2Nk-1)^2-tap kernel f' (*) c' (weight_kernels.hip) is dD*dD planes written and read once.
         double cf_bytes = 0;
         for (int l = 0; l < n->L; ++l) cf_bytes += 2.0 * n->pr[l].dM * n->pr[l].dD * n->pr[l].P * 8.0;
-        bool ok = (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && !fused_upd /* the taps are stored */ && !flag(AEFFT_F_NOQPATH) && n->L <= 8 && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
-        for (int l = 0; l < n->L && ok; ++l) { const Pair& q = n->pr[l]; ok = q.Q && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nk && (double)q.dD * q.dD * q.P * 8.0 < 4294967296.0; }
-        if (ok) {
-            GspGroup gg{};
-            PrunedGroup pg{};
-            const int T = 2 * n->pr[0].Nk - 1;
-            double gbytes = 0, kbytes = 0;
-            for (int l = 0; l < n->L; ++l) {
-                Pair& q = n->pr[l];
-                gg.q[l] = GspProb{q.c, q.f, q.Q, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};     // Q is dead after the weight gradients: reused for the taps
-                pg.q[l] = PrunedProb{q.Q, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
-                gbytes += (2.0 * q.dM * q.dD * q.Nk * q.Nl + (double)q.dD * q.dD * T * T) * 4.0;
-                kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
-            }
-            gg.n = pg.n = n->L;
-            hipError_t e;
-            {
-                Bracket br(ctx, KID_WGRAD, gbytes);
-                e = launch_gspatial_group(gg, n->pr[0].Nk, ctx->cur);
-            }
-            if (e == hipSuccess) {
-                Bracket br(ctx, KID_KSPEC, kbytes);
-                e = launch_kspec_group_taps(pg, ctx->tw, T, ctx->cur);
-            }
-            if (e == hipSuccess) g_taps = true;
-            else if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G'(taps)", e);
-            else (void)hipGetLastError();
-        }
+        const bool want = (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && !fused_upd /* the taps are stored */ && !flag(AEFFT_F_NOQPATH);
+        if (want) RET_IF(gprime_from_taps(n, &g_taps));
     }
     if (op_mode(n)) {
         // post-update MSE (fft_backproplib.cu:1460-1463) in operator form: R = A - F'(C' A / dM + b^) / dD - p^ per bin, then
@@ -2162,36 +2177,8 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             const bool noq = flag(AEFFT_F_NOQPATH);
             double cf_bytes = 0;
             for (int l = 0; l < n->L; ++l) cf_bytes += 2.0 * n->pr[l].dM * n->pr[l].dD * n->pr[l].P * 8.0;
-            bool gtaps = !noq && (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && m == n->L && n->pr[0].Nk == n->pr[0].Nl && (n->pr[0].Nk == 3 || n->pr[0].Nk == 5);
-            for (int l = 0; l < n->L && gtaps; ++l) { const Pair& q = n->pr[l]; gtaps = q.Q && q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl; }
-            if (gtaps) {
-                GspGroup gg{};
-                PrunedGroup pg{};
-                const int T = 2 * n->pr[0].Nk - 1;
-                double gbytes = 0, kbytes = 0;
-                for (int l = 0; l < n->L; ++l) {
-                    Pair& q = n->pr[l];
-                    gg.q[l] = GspProb{q.c, q.f, q.Q, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};     // Q is dead after the weight gradients: reused for gsp
-                    pg.q[l] = PrunedProb{q.Q, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f};
-                    gbytes += (2.0 * q.dM * q.dD * q.Nk * q.Nl + (double)q.dD * q.dD * T * T) * 4.0;
-                    kbytes += (double)q.dD * q.dD * (q.P * 8.0 + T * T * 4.0);
-                }
-                gg.n = pg.n = n->L;
-                hipError_t e;
-                {
-                    Bracket br(ctx, KID_WGRAD, gbytes);
-                    e = launch_gspatial_group(gg, n->pr[0].Nk, ctx->cur);
-                }
-                if (e == hipSuccess) {
-                    Bracket br(ctx, KID_KSPEC, kbytes);
-                    e = launch_kspec_group_taps(pg, ctx->tw, T, ctx->cur);
-                }
-                if (e != hipSuccess) {
-                    if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G(taps)", e);
-                    (void)hipGetLastError();
-                    gtaps = false;
-                }
-            }
+            bool gtaps = false;
+            if (!noq && (cf_bytes > 256e6 || flag(AEFFT_F_GTAPS)) && m == n->L) RET_IF(gprime_from_taps(n, &gtaps));
             if (!gtaps) RET_IF(do_contract_group(ctx, gq, m, m, 0));
             ContractN g{};
             double bytes = 0;
@@ -2284,6 +2271,14 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     n->have_grad = true;
     if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
     return mark_step_point(n);
+}
+
+extern "C" int aefft_net_step_form(aefft_net* n)
+{
+    if (!n) return -1;
+    if (!op_eligible(n)) return AEFFT_FORM_PER_FRAME;
+    const bool chain = n->Wp && (n->compact || n->L == 1) && chain_switches_ok();
+    return chain ? AEFFT_FORM_OPERATOR_CHAIN : AEFFT_FORM_OPERATOR;
 }
 
 extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloats)

@@ -136,15 +136,11 @@ hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, 
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st);
 // the inverse transform on a T x T support with T = 5 or 9 (the offsets kl + k'l' of 3x3 / 5x5 kernels, weight_kernels.hip)
 hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias = nullptr /* fused: the DC-bin terms as extra workgroups */);
-hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);
 
 // ---- weight_kernels.hip ----------------------------------------------------------------
 struct WgradProb { const float *c, *f, *Q, *es, *b; float *gc, *gf; int dM, dD; float inv_den, norm; int nq; };   // Q [dD][dD][nq][T*T] (nq row-chunk partial sums, added here), es [2*dD]
 struct WgradGroup { WgradProb q[8]; int n; int start[9]; };
 hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st);
-struct GspProb { const float *c, *f; float* gsp; int dM, dD; float scale; };                                // gsp [dD][dD][T*T]
-struct GspGroup { GspProb q[8]; int n; int start[9]; };
-hipError_t launch_gspatial_group(GspGroup& g, int Nk, hipStream_t st);
 
 const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()
 

@@ -938,7 +938,6 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
     for (int l = 0; l < g.L; ++l) {
         if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX) return hipErrorInvalidValue;
-        if (((g.lv[l].dD * g.lv[l].dM + 1) & ~1) > CH_WL) return hipErrorInvalidValue;
         if (l + 1 < g.L && (size_t)2 * g.lv[l].dM * OPC * CH_BT > CH_WL) return hipErrorInvalidValue;     // planar tiles: two V tiles share the LDS buffer
     }
     long total = g.Pc;

@@ -755,13 +755,6 @@ static bool taps_group_ok(const PrunedGroup& g, const float2* tw)
     }
     return true;
 }
-hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st)
-{
-    if (!taps_group_ok(g, tw)) return hipErrorInvalidValue;
-    if (T == 5) return run_kspec_group<5, 5>(g, tw, st);
-    if (T == 9) return run_kspec_group<9, 9>(g, tw, st);
-    return hipErrorInvalidValue;
-}
 hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias)
 {
     if (!taps_group_ok(g, tw) || (bias && (bias->n < 1 || bias->n > 8))) return hipErrorInvalidValue;

@@ -9,9 +9,8 @@
 //     g_c[m][d][kl] = sum_d1 sum_k'l' f[d1][m][k'l'] Q[d1][d][kl + k'l'] / (Norm B)
 //     g_f[d][m][kl] = ( sum_d1 sum_k'l' c[m][d1][k'l'] Q[d][d1][kl + k'l'] + Re es[d] b[m] Nx Ny ) / (Norm B)
 // (same sums, re-associated: float32 rounding only).  The dM*dD-plane gradient spectra dc|df (64 MB written and read
-// back per step at cfg3) never exist.  Likewise the per-bin product G = F.C/(dM dD) used by the post-update MSE is the
-// spectrum of the (2Nk-1) x (2Nl-1) kernel gsp[d'][d] = sum_m f[d'][m] (*) c[m][d] / (dM dD): for HBM-sized kernel spectra
-// (no pooling) forming gsp here and transforming dD*dD planes replaces a read of all 2*dM*dD planes of C|F.
+// back per step at cfg3) never exist.  (Likewise the per-bin product G = F.C/(dM dD) used by the post-update MSE is the
+// spectrum of the (2Nk-1) x (2Nl-1) kernel sum_m f[d'][m] (*) c[m][d] / (dM dD): gspec_gbody, pruned_kernels.hip.)
 #include "internal.h"
 #include <algorithm>
 
@@ -167,78 +166,6 @@ hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
     }
     if (Nk == 3) wgrad_taps_kernel<3><<<dim3(total), 256, lds, st>>>(g);
     else wgrad_taps_kernel<5><<<dim3(total), 256, lds, st>>>(g);
-    return hipGetLastError();
-}
-
-// gsp[d'][d][tx][ty] = scale * sum_m sum_{k,l} f[d'][m][k][l] * c[m][d][tx-k][ty-l].  Workgroup = (d', tile of TD d's);
-// f[d'][.][.] and the tile's c[.][d][.] are staged in LDS; thread <-> (d in tile, output row tx) owns the T outputs of
-// that row: per (m, k) one row of f and one row of c (NK floats each) feed a full 1-D convolution in registers
-// (rows outside the kernel are read clamped and weighted by zero: branch-free).
-template <int NK>
-__global__ __launch_bounds__(256) void gspatial_kernel(const GspGroup g)
-{
-    constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, TD = 256 / T;           // 28 d's per workgroup for 5x5
-    extern __shared__ float sh[];                       // fs[dM][KK] | cs[dM][TD][KK]
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
-    const GspProb& q = g.q[p];
-    const int dM = q.dM, dD = q.dD;
-    const int dt = (dD + TD - 1) / TD;
-    const int blk = blockIdx.x - g.start[p];
-    const int dp = blk / dt, d0 = (blk - dp * dt) * TD;
-    float* fs = sh;
-    float* cs = sh + dM * KK;
-    const int dl = threadIdx.x / T, tx = threadIdx.x - dl * T;
-    const bool active = dl < TD && d0 + dl < dD;
-    float acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    constexpr int MC = 16;                               // m's staged per pass (LDS budget)
-    for (int mc = 0; mc < dM; mc += MC) {
-        const int nm = min(MC, dM - mc);
-        __syncthreads();
-        for (int t = threadIdx.x; t < nm * KK; t += 256) fs[t] = q.f[((long)dp * dM + mc) * KK + t];
-        for (int t = threadIdx.x; t < nm * TD * KK; t += 256) {
-            const int m = t / (TD * KK), rem = t - m * (TD * KK);
-            const int d2 = rem / KK, r = rem - d2 * KK;
-            cs[t] = d0 + d2 < dD ? q.c[((long)(mc + m) * dD + d0 + d2) * KK + r] : 0.f;
-        }
-        __syncthreads();
-        if (!active) continue;
-        for (int m = 0; m < nm; ++m) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int k2 = tx - k;
-                const bool ok = k2 >= 0 && k2 < NK;
-                const float* fr = fs + m * KK + k * NK;
-                const float* cr = cs + (m * TD + dl) * KK + (ok ? k2 : 0) * NK;
-                float f5[NK], c5[NK];
-#pragma unroll
-                for (int l = 0; l < NK; ++l) { f5[l] = ok ? fr[l] : 0.f; c5[l] = cr[l]; }
-#pragma unroll
-                for (int l = 0; l < NK; ++l)
-#pragma unroll
-                    for (int l2 = 0; l2 < NK; ++l2) acc[l + l2] = fmaf(f5[l], c5[l2], acc[l + l2]);
-            }
-        }
-    }
-    if (!active) return;
-    float* dst = q.gsp + ((long)dp * dD + d0 + dl) * TT + tx * T;
-#pragma unroll
-    for (int t = 0; t < T; ++t) dst[t] = acc[t] * q.scale;
-}
-
-hipError_t launch_gspatial_group(GspGroup& g, int Nk, hipStream_t st)
-{
-    if (g.n < 1 || g.n > 8 || (Nk != 3 && Nk != 5)) return hipErrorInvalidValue;
-    const int KK = Nk * Nk, T = 2 * Nk - 1, TD = 256 / T, MC = 16;
-    int total = 0;
-    for (int i = 0; i < g.n; ++i) { const GspProb& q = g.q[i]; g.start[i] = total; total += q.dD * ((q.dD + TD - 1) / TD); }
-    g.start[g.n] = total;
-    const size_t lds = sizeof(float) * ((size_t)MC * KK + (size_t)MC * TD * KK);
-    if (Nk == 3) gspatial_kernel<3><<<dim3(total), 256, lds, st>>>(g);
-    else gspatial_kernel<5><<<dim3(total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 

@@ -49,9 +49,11 @@ const char* aefft_last_error(const aefft_ctx* ctx);
 int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* aefft_stream(aefft_ctx* ctx);             /* the hipStream_t in use */
 /* Development switches: each bit turns ONE optimisation of the training step off (or forces one the shapes would not choose), so
- * that the parity tests can run every fallback against the oracle.  Process-wide; the default is 0.  The environment variable
- * AEFFT_FLAGS (comma-separated names without the AEFFT_F_ prefix, e.g. "NOMFMA,NOGROUP") is read ONCE, when the first context is
- * created; the library never calls getenv after that. */
+ * that the parity tests can run every fallback against the oracle.  Process-wide (one word for every context); the default is 0.  The
+ * environment variable AEFFT_FLAGS (comma-separated names without the AEFFT_F_ prefix, e.g. "NOMFMA,NOGROUP") is read ONCE, when the
+ * first context is created; the library never calls getenv after that.  Its switches stay on for the life of the process:
+ * aefft_ctx_set_flags sets the word to (AEFFT_FLAGS | flags).  A name in AEFFT_FLAGS that the library does not know makes
+ * aefft_ctx_create fail with AEFFT_EINVAL (message on stderr) instead of silently running the default path. */
 enum {
     AEFFT_F_NOLAZY = 1 << 0,      /* encoder layers on the full grid even when only their pooled part is consumed */
     AEFFT_F_NOCOMPACT = 1 << 1,   /* decoder outputs on the full grid instead of the support of the up-sampled spectra */
@@ -189,7 +191,16 @@ int aefft_net_load_spectra(aefft_net* net, int l, const float* C_h, const float*
 int aefft_net_forward(aefft_net* net, const float* frames_d, float* recon_d);
 /* fft_l=1 semantics (:1347,1357,1361): coordinate-space copy of reference layer index `layer`
  * (autoencoder.cpp:110-114 ordering, 0..4L) from the last forward.  out_d [B][ch][nx][ny];
- * ch/nx/ny (nullable) receive its shape.  Pass out_d=NULL to query the shape only. */
+ * ch/nx/ny (nullable) receive its shape.  Pass out_d=NULL to query the shape only.
+ * After aefft_net_step_grad (with or without the following aefft_net_step_apply) the layers are those of THAT step's forward, i.e. of the
+ * weights before the update.  What they are formed from depends on the step form (aefft_net_step_form):
+ *   OPERATOR_CHAIN  the resident input spectra and the step's stored operators -- neither the caller's frame buffer nor the current
+ *                   weights enter (layer 0, the input itself, is copied from the frame buffer of the last step_grad / forward);
+ *   OPERATOR        the per-frame forward of the frames of the last step_grad is re-run with the CURRENT weights: the caller's frame buffer
+ *                   must still hold them, and after aefft_net_step_apply the layers are those of the updated weights;
+ *   PER_FRAME       the spectra of the step's forward as stored.
+ * In every form a HIDDEN layer (even index <= 2L) that the training step did not materialise is formed on request from the pair's input
+ * of the step and the pair's CURRENT encoder. */
 int aefft_net_get_layer(aefft_net* net, int layer, float* out_d, int* ch, int* nx, int* ny);
 
 /* fft_l = 1 in one call: EVERY layer 0..4L of the last forward, coordinate space, packed into out_d at the
@@ -234,6 +245,18 @@ int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
  * Default 0: everything is ordered on the context stream and recon_d is complete when aefft_net_step_grad's work is. */
 int aefft_net_set_input_ready(aefft_net* net, int enable);
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
+/* Which form the NEXT aefft_net_step_grad / _apply of this net runs in (decided by the net's shapes and the development switches; the
+ * arithmetic is the reference's in every form, re-associated -- DESIGN.md section 4):
+ *   AEFFT_FORM_PER_FRAME       every layer evaluated for every frame (batch contractions on the matrix cores).  Taken for inputs of more
+ *                              than 3 channels, kernel supports other than equal square 3x3 / 5x5, channel counts beyond the operator
+ *                              kernels' tiles, and under AEFFT_F_NOOPFORM / AEFFT_F_NOQPATH.
+ *   AEFFT_FORM_OPERATOR        the network is linear: layers evaluated once per step as per-bin operators on 4 basis frames, the batch
+ *                              enters through the input transform, its centred second moments and the reconstruction; layer by layer.
+ *   AEFFT_FORM_OPERATOR_CHAIN  ... with the whole operator chain in one launch out of a bin-major copy of the kernel spectra (coarsest grid
+ *                              of at most 16384 bins); the next step's chain rides in the last launch of this step.
+ * Returns -1 for a null net. */
+enum { AEFFT_FORM_PER_FRAME = 0, AEFFT_FORM_OPERATOR = 1, AEFFT_FORM_OPERATOR_CHAIN = 2 };
+int aefft_net_step_form(aefft_net* net);
 int aefft_net_step_apply(aefft_net* net, float del0, int maxdiff, int sym, float grad_scale, float* mse_d);
 int aefft_net_reset_momentum(aefft_net* net);
 

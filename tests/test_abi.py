@@ -75,3 +75,12 @@ def test_product_does_not_touch_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "np_ref" not in txt and "cpu_ref" not in txt and "oracle/" not in txt.replace("oracle/ ", ""), (dp, fn)
+
+
+def test_unknown_name_in_AEFFT_FLAGS_fails_context_creation(built):
+    """a typo in AEFFT_FLAGS must not silently run the default path: the first aefft_ctx_create returns AEFFT_EINVAL"""
+    import sys
+    code = ("import ctypes as C, importlib, sys; sys.path.insert(0, %r); m = importlib.import_module('autoencoder-fft_amd'); L = m.lib(); "
+            "h = C.c_void_p(); print(L.aefft_ctx_create(C.byref(h), 0, None, 1))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AEFFT_FLAGS="NOMFMA,BOGUS"))
+    assert out.stdout.strip().endswith("1") and "BOGUS" in out.stderr, (out.stdout, out.stderr)
