@@ -1056,7 +1056,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->real, n->pruned ? 64 : maxReal)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->mse_slots, (size_t)n->L * MSE_SLOTS * MSE_SLOT_STRIDE)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->grad, goff)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
+            (rc = net_alloc_t(n, &n->grad, goff + (size_t)n->L)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
             n->scratch_n = soff; n->mse_pre = n->scratch; n->mse_post = n->scratch + n->L;
             for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
             n->grad_n = goff;
@@ -1086,6 +1086,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     }
     if (rc != AEFFT_OK) { aefft_net_destroy(n); return rc; }
     hipError_t e = hipMemsetAsync(n->mse_slots, 0, sizeof(float) * n->L * MSE_SLOTS * MSE_SLOT_STRIDE, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(n->grad + n->grad_n, 0, sizeof(float) * n->L, ctx->stream);      // (the MSE tail of the packed buffer: zero before the first step)
     if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset(mse slots)", e); }
     for (auto& q : n->pr) {
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
@@ -1980,7 +1981,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change
     n->packed_valid = false; n->chain_valid = false;
     const bool nogroup1 = flag(AEFFT_F_NOGROUP);
-    bool fused_upd = false;                                                // the tap half of the update rides with mse_finish (below)
+    bool fused_upd = false;                                                // the tap half of the update rides in the tail launch (below)
     bool gp_route = false;                                                 // the spectra launch wrote G' = F'.C'/(dM dD) for every pair but the innermost
     UpdateGroup wupd{};
     bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
@@ -2004,7 +2005,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         const bool ride = op_mode(n) && n->Wp != nullptr;                  // the bin-major copy for the next step's chain: same taps, same launch
         // Fused update (operator form, plain gradients): no update launch.  The spectra launch reads every tap THROUGH the pending
         // update (w - clip_step(g, D): TapUpd) and carries the bias half as a trailing workgroup per pair; the taps and their momentum
-        // are stored in place by trailing workgroups of the step's last launch (mse_finish) -- nothing in between reads them.
+        // are stored in place by trailing workgroups of the tail launch (tail_kernel) -- nothing in between reads them.
         fused_upd = ride && !sym && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
         // Operator form with the chain launch: NO planar spectra are written.  The next step's chain reads the bin-major record Wp
         // and the compact planes Cc_l (C_l where the next pair's grid lands); the post-update MSE reads G'_l = F'_l.C'_l/(dM dD) --
@@ -2148,7 +2149,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         if (ahead) { n->op_set ^= 1; n->chain_valid = true; }
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, nullptr);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, n->grad + n->grad_n);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
         return AEFFT_OK;
     }
@@ -2205,7 +2206,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         Pair& ql = n->pr[n->L - 1];
         BetaArgs ba{ql.beta, ql.F, ql.b, ql.p, ql.dM, ql.dD, ql.P};
         const bool want_beta = g_in_S[n->L - 1] && ql.beta && ql.dD <= 256;
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, want_beta ? &ba : nullptr);     // also the copy-out to mse_d
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, want_beta ? &ba : nullptr, n->grad + n->grad_n);     // also the copy-out to mse_d and to the packed buffer's tail
         ql.G_valid = want_beta && e == hipSuccess;
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
     }
@@ -2285,7 +2286,7 @@ extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloat
 {
     if (!n) return AEFFT_EINVAL;
     if (buf_d) *buf_d = n->grad;
-    if (nfloats) *nfloats = n->grad_n;
+    if (nfloats) *nfloats = n->grad_n + (size_t)n->L;
     return AEFFT_OK;
 }
 

@@ -74,9 +74,8 @@ struct Contract {
 };
 enum { MSE_SLOTS = 256, MSE_SLOT_STRIDE = 16 };
 struct BetaArgs { float* beta; const float2* F; const float *b, *p; int dM, dD; long P; };     // beta == null: off
-struct UpdateGroup;
 hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st,
-                             const BetaArgs* beta = nullptr, const UpdateGroup* weights_upd = nullptr /* the tap half of a fused update as trailing workgroups */);
+                             const BetaArgs* beta = nullptr, float* copy2 = nullptr /*[L] nullable: a second copy (the tail of the packed gradient buffer)*/);
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 // Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):

@@ -777,22 +777,11 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 // sums (and clears) the slot accumulators of the MSE epilogue: out[l] += sum, copy[l] = out[l].  Optionally also forms the
 // DC-bin bias of the collapsed pair operator O = G X + beta (conv_k o conv_k, fft.cu:183-184 twice):
 //   beta[d'] = p[d'] + sum_m F[d'][m](0,0) b[m] / dD          (times Nx*Ny where it is applied)
-__global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, int L,
-                                                               const BetaArgs ba, const UpdateGroup ug, const int nfin)
+__global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, float* __restrict__ copy2, int L,
+                                                               const BetaArgs ba)
 {
     __shared__ float ws[MSE_SLOTS / 64];
     __shared__ float bacc[256];
-    if ((int)blockIdx.x >= nfin) {
-        // trailing workgroups: the tap half of a fused update, in place (the spectra of the new taps exist already: kspec read them
-        // through the update; nothing later in the step reads the taps)
-        static_assert(MSE_SLOTS == 256, "update blocks are 256 elements");
-        const int blk = blockIdx.x - nfin;
-        int p = 0;
-#pragma unroll
-        for (int i = 1; i < 8; ++i) if (i < ug.n && blk >= ug.start[i]) p = i;
-        update_weights_part(ug.a[p], blk - ug.start[p]);
-        return;
-    }
     if (blockIdx.x == 1) {                               // second workgroup (only launched when beta is wanted): runs beside the sums
         for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) bacc[d] = 0.f;
         __syncthreads();
@@ -817,25 +806,17 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
             for (int w = 0; w < MSE_SLOTS / 64; ++w) t += ws[w];
             out[l] = t;
             if (copy) copy[l] = t;
+            if (copy2) copy2[l] = t;
         }
         __syncthreads();
     }
 }
 
-static UpdateGroup g_ug_none{};
-hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba, const UpdateGroup* wu)
+hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba, float* copy2)
 {
     BetaArgs a{};
     if (ba && ba->dD <= 256) a = *ba;
-    const int nfin = a.beta ? 2 : 1;
-    int nupd = 0;
-    UpdateGroup ug = g_ug_none;
-    if (wu && wu->n > 0) {
-        ug = *wu;
-        for (int i = 0; i < ug.n; ++i) { ug.start[i] = nupd; nupd += (ug.a[i].dM * ug.a[i].dD * ug.a[i].Nk * ug.a[i].Nl + 255) / 256; }
-        ug.start[ug.n] = nupd;
-    }
-    mse_finish_kernel<<<nfin + nupd, MSE_SLOTS, 0, st>>>(slots, out, copy, L, a, ug, nfin);
+    mse_finish_kernel<<<a.beta ? 2 : 1, MSE_SLOTS, 0, st>>>(slots, out, copy, copy2, L, a);
     return hipGetLastError();
 }
 

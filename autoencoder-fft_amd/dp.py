@@ -6,19 +6,31 @@ per frame; C2R and shrink are linear, so every rank reduces its own frames to th
 packed buffer  [dck | dfk | db | dp] per pair  (aefft_net_grad_buffer), ONE all-reduce(SUM) of that buffer
 (0.54 MB for the 4-pair 512x512 network) is followed by the identical clipped-momentum update on every
 rank with grad_scale = 1/world.  Weights stay replicated bit-for-bit because every rank applies the same
-float32 update to the same all-reduced buffer."""
+float32 update to the same all-reduced buffer.
+
+The MSE rides in the same message (SURVEY 8e "+ 1 float MSE"): the packed buffer ends in L floats, the post-update MSE per pair of
+this rank's shard as the PREVIOUS step left it (aefft_net_step_apply writes them there; the post-update MSE of a step needs that
+step's reduced gradients, so it cannot travel with them).  After the all-reduce that tail holds the sum over ranks; mse_tail() turns
+it into the global-batch mean (one step behind), and flush_mse() reduces the last step's values with one more small collective."""
 import numpy as np
 
 
 def grad_layout(dims):
     """Offsets (in floats) of each pair's segments inside the packed gradient buffer; mirrors
-    aefft_net_create (aefft_capi.hip: goff += 2*nk + dM + dD).  dims: list of dict(dM, dD, Nk, Nl)."""
+    aefft_net_create (aefft_capi.hip: goff += 2*nk + dM + dD).  dims: list of dict(dM, dD, Nk, Nl).
+    Returns (layout, n): n = floats of the gradient part; the buffer the library exposes is n + len(dims) long (mse_tail_slice)."""
     out, off = [], 0
     for g in dims:
         nk = g["dM"] * g["dD"] * g["Nk"] * g["Nl"]
         out.append(dict(dck=(off, nk), dfk=(off + nk, nk), db=(off + 2 * nk, g["dM"]), dp=(off + 2 * nk + g["dM"], g["dD"])))
         off += 2 * nk + g["dM"] + g["dD"]
     return out, off
+
+
+def mse_tail_slice(dims):
+    """Where the per-pair post-update MSEs of the previous step sit in the packed buffer (aefft_net_grad_buffer: nfloats = gradients + L)."""
+    _, n = grad_layout(dims)
+    return slice(n, n + len(dims))
 
 
 def pack_grads(per_pair, dims):
@@ -56,15 +68,53 @@ class DataParallelStep:
     def __init__(self, net, group=None):
         self.net, self.group = net, group
         self.gbuf = net.grad_buffer()
+        self.tail = mse_tail_slice(net.dims)
+        assert self.gbuf.numel() == self.tail.stop, "packed buffer: gradients + one MSE float per pair"
+        self._mse_prev = None            # global-batch MSE of the step before the last __call__ (device tensor, stream-ordered)
+        self._scale = 1.0
+        self.timers = None               # set to a list to collect (grad_ms, allreduce_ms, apply_ms) per step (events on the library's stream)
 
     def __call__(self, frames, recon, del0, maxdiff=0, sym=0, mse=None):
+        import torch
+        st = self.net.ctx.torch_stream()
+        ev = None
+        if self.timers is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(st)
         self.net.step_grad(frames, recon)
         # the collective is enqueued on the library's own stream: gradients -> all-reduce -> update stay ordered
         # without any host synchronisation
+        with torch.cuda.stream(st):
+            if ev: ev[1].record(st)
+            scale = allreduce_sum_(self.gbuf, self.group)
+            if ev: ev[2].record(st)
+            # the tail now holds the sum over ranks of the previous step's post-update MSEs: keep the global mean before
+            # aefft_net_step_apply overwrites the tail with this step's local values
+            self._mse_prev = self.gbuf[self.tail] * scale
+        self._scale = scale
+        self.net.step_apply(del0, maxdiff, sym, scale, mse)
+        if ev:
+            ev[3].record(st)
+            self.timers.append(ev)
+
+    def mse_tail(self):
+        """global-batch post-update MSE per pair of the step BEFORE the last one (it travelled in the last gradient all-reduce); None before the second step"""
+        return self._mse_prev
+
+    def flush_mse(self):
+        """global-batch post-update MSE per pair of the LAST step: one small all-reduce of the buffer's tail (end of training / logging points)"""
         import torch
         with torch.cuda.stream(self.net.ctx.torch_stream()):
-            scale = allreduce_sum_(self.gbuf, self.group)
-        self.net.step_apply(del0, maxdiff, sym, scale, mse)
+            t = self.gbuf[self.tail].clone()
+            scale = allreduce_sum_(t, self.group)
+            return t * scale
+
+    def phase_ms(self):
+        """mean (grad half, all-reduce, apply half) milliseconds over the steps recorded in self.timers (synchronises)"""
+        import torch
+        torch.cuda.synchronize()
+        n = max(len(self.timers), 1)
+        return [sum(e[i].elapsed_time(e[i + 1]) for e in self.timers) / n for i in range(3)]
 
     def replicas_agree(self):
         """All ranks hold identical weights (checksum of every pair's tensors, all-gathered)."""

@@ -244,6 +244,12 @@ int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
  * on the context stream only after the following aefft_net_step_apply, aefft_sync or any later call on the net.
  * Default 0: everything is ordered on the context stream and recon_d is complete when aefft_net_step_grad's work is. */
 int aefft_net_set_input_ready(aefft_net* net, int enable);
+/* The packed buffer (device), nfloats = [dck | dfk | db | dp of pair 0] ... [of pair L-1] | mse[L]: the batch-mean gradients of the last
+ * aefft_net_step_grad, then ONE float per pair: the post-update MSE of this rank's frames as the PREVIOUS aefft_net_step_apply left it
+ * (zero before the first).  A data-parallel caller all-reduces (SUM) the whole buffer: the gradients are then applied with grad_scale =
+ * 1/world, and the tail times 1/world is the global-batch MSE of the previous step (the MSE rides in the gradients' message;
+ * the post-update MSE of a step needs that step's reduced gradients, so it travels one step behind).  aefft_net_step_apply reads the
+ * gradient part only and overwrites the tail. */
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 /* Which form the NEXT aefft_net_step_grad / _apply of this net runs in (decided by the net's shapes and the development switches; the
  * arithmetic is the reference's in every form, re-associated -- DESIGN.md section 4):

@@ -64,11 +64,14 @@ def _worker(rank, world, port, q):
     dp = importlib.import_module("autoencoder-fft_amd.dp")
     R, xs, ws, dims, sp, L = _problem()
     shard = list(range(rank * len(xs) // world, (rank + 1) * len(xs) // world))
-    buf = torch.from_numpy(dp.pack_grads(_local_grads(R, sp, ws, dims, L, shard), dims))
+    # the packed buffer as the library exposes it: gradients, then one post-update MSE per pair of the previous step on this rank
+    local_mse = np.array([10.0 * rank + l + 1 for l in range(L)], np.float32)
+    buf = torch.from_numpy(np.concatenate([dp.pack_grads(_local_grads(R, sp, ws, dims, L, shard), dims), local_mse]))
     scale = dp.allreduce_sum_(buf)
     grads = [tuple(scale * a.astype(np.float64) for a in g) for g in dp.unpack_grads(buf.numpy(), dims)]
     new = _update(R, ws, grads, 0.02)
-    q.put((rank, [[a.copy() for a in t] for t in new]))
+    tail = buf.numpy()[dp.mse_tail_slice(dims)] * scale            # global-batch mean of the MSEs (the MSE rides in the same all-reduce)
+    q.put((rank, [[a.copy() for a in t] for t in new], tail.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,7 +83,10 @@ def test_two_rank_data_parallel_equals_single_process_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=180) for _ in range(world))
+    res = [q.get(timeout=180) for _ in range(world)]
+    got = {r[0]: r[1] for r in res}
+    for r in res:                                                          # every rank reads the same global mean: (l+1 + 10+l+1) / 2
+        assert np.allclose(r[2], [5.0 + l + 1 for l in range(len(r[2]))])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -278,3 +278,17 @@ def test_config5_full_size_default_equals_literal(ctx, flags):
         for x, y in zip(a[1:], b_[1:]):
             assert np.abs(x - y).max() < 4.1e-3, l
     assert np.allclose(m_lit, m_opt, rtol=2e-4), (m_lit, m_opt)
+
+
+def test_c_level_step_with_rccl_on_the_library_stream():
+    """INTEGRATION.md section 3 from plain C++ (examples/rccl_step.cpp, no torch): aefft_net_step_grad -> ncclAllReduce of
+    aefft_net_grad_buffer on aefft_stream(ctx) -> aefft_net_step_apply, world size 1 (the only size a one-GPU box allows): the
+    collective and both halves ordered on the library's stream, the packed buffer's MSE tail = the previous step's MSE, weights equal
+    to a net trained without the collective."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "autoencoder-fft_amd", "aefft_rccl_step")
+    assert os.path.exists(exe), "build it: make -C autoencoder-fft_amd/csrc rccl_step (__graft_entry__.build does)"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl_step ok" in out.stdout, (out.stdout, out.stderr[-2000:])
