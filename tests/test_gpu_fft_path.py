@@ -319,7 +319,8 @@ def test_second_step_equals_fresh_net_with_updated_weights(ctx, path, flags):
     fresh.step_grad(x2, r_fresh)
     g_fresh = host(fresh.grad_buffer())
     assert relerr(host(r_live), host(r_fresh)) < 2e-5
-    assert relerr(g_live, g_fresh) < 5e-5
+    # the last L floats of the packed buffer carry the PREVIOUS step's post-update MSEs (zero on a fresh net): not compared
+    assert relerr(g_live[:-L], g_fresh[:-L]) < 5e-5
     for a, b in zip(layers_live, [host(fresh.get_layer(l)) for l in range(1, 4 * L + 1)]):
         assert relerr(a, b) < 5e-5
     net.close(); fresh.close()
