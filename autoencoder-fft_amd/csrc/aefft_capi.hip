@@ -636,7 +636,7 @@ static int do_update(aefft_ctx* ctx, float* c, float* f, float* b, float* p, con
         const size_t nk = (size_t)dM * dD * Nk * Nl;
         void *small, *den;
         RET_IF(ws_get(ctx, WS_SMALL, sizeof(float) * (2 * nk + dM + dD + 64), &small));
-        RET_IF(ws_get(ctx, WS_DEN, sizeof(float) * 2 * (size_t)dM * dD * dM * dD, &den));
+        RET_IF(ws_get(ctx, WS_DEN, sizeof(float) * gradient_diff_ws_floats(dM, dD, Nk, Nl), &den));
         float* cd = (float*)small; float* fd = cd + nk; float* bd = fd + nk; float* pd = bd + dM;
         {
             Bracket br(ctx, KID_GDIFF, (double)nk * 16.0);
@@ -1042,7 +1042,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
         esoff[l] = soff; soff += 2 * (size_t)q.dD;
         maxReal = std::max(maxReal, (size_t)q.dM * q.dD * q.Nx * q.Ny);
         maxMid = std::max(maxMid, (size_t)q.dM * q.dD * q.Nx * (q.Ny / 2));
-        maxDen = std::max(maxDen, 2 * (size_t)q.dM * q.dD * q.dM * q.dD);
+        maxDen = std::max(maxDen, gradient_diff_ws_floats(q.dM, q.dD, q.Nk, q.Nl));
         maxSmall = std::max(maxSmall, 2 * nk + q.dM + q.dD + 64);
         dD = q.dM; nx = q.Nx; ny = q.Ny;
     }

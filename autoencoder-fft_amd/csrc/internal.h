@@ -221,6 +221,7 @@ struct UpdateArgs {
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 struct UpdateGroup { UpdateArgs a[8]; int n; int start[9]; };
 hipError_t launch_update_group(UpdateGroup& g, hipStream_t st);                                       // up to 8 pairs, one launch                                      // fft.cu:605 / 657
+size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl);      // floats of launch_gradient_diff's workspace (chunk partial sums)
 hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
                                 float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st);   // fft.cu:709
 

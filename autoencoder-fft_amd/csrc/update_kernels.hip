@@ -99,11 +99,90 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------
-// gradient_diff (fft_backproplib.cu:709-753).  The reference recomputes the squared kernel
-// distance den(m,d;m1,d1) inside every (k,l) thread; here it is computed once per kernel pair
-// (same k1,l1 summation order, so identical floats) into `den_ws` = 2*(dM*dD)^2 floats, then
-// each (m,d,k,l) thread sums (w - w1)/den over the partners in the reference's (m1,d1) order.
+// gradient_diff (fft_backproplib.cu:709-753):
+//   cd[m][d][r] = sum_{m1 != m, d1 != d} (c[m][d][r] - c[m1][d1][r]) / |c[m][d] - c[m1][d1]|^2      (same for f, b, p)
+// The reference recomputes the squared kernel distance inside every (k,l) thread and divides per tap: O((dM dD)^2 (Nk Nl)^2).
+// Here a thread owns one kernel a = (m,d) -- its KL taps and KL running sums in registers -- and walks a chunk of partners whose
+// taps every thread of the workgroup reads from LDS at the same address (broadcast): per partner KL subtractions, KL FMAs for the
+// distance, ONE reciprocal, KL FMAs for the sums.  The partner range is cut into chunks (grid y) so that the small tensors still
+// fill the chip; the chunks' partial sums lie side by side and gdiff_finish_kernel adds them in chunk order (deterministic: the
+// replicas of a data-parallel run must stay bit-identical).  No (dM dD)^2 distance matrix is stored (537 MB at cfg5's 64->128 pair).
 // ------------------------------------------------------------------------------------------
+template <int KL>
+__global__ __launch_bounds__(256) void gdiff_part_kernel(const float* __restrict__ c, const float* __restrict__ f, float* __restrict__ part,
+                                                         int dM, int dD, int chunk)
+{
+    constexpr int KP = (KL + 3) & ~3;                      // LDS row pitch: whole float4s
+    extern __shared__ float4 gd_sh4[];
+    float* sh = reinterpret_cast<float*>(gd_sh4);
+    const int np = dM * dD;
+    const bool isf = blockIdx.z != 0;                      // rows of f are (d,m)-ordered, rows of c (m,d)-ordered
+    const float* __restrict__ w = isf ? f : c;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * chunk, j1 = min(np, j0 + chunk);
+    // partner taps -> LDS (coalesced), zero padding of the pitch
+    for (int t = threadIdx.x; t < (j1 - j0) * KP; t += 256) {
+        const int j = t / KP, r = t - j * KP;
+        sh[t] = r < KL ? w[(long)(j0 + j) * KL + r] : 0.f;
+    }
+    float ca[KL], acc[KL];
+    const int ii = min(i, np - 1);
+#pragma unroll
+    for (int r = 0; r < KL; ++r) { ca[r] = w[(long)ii * KL + r]; acc[r] = 0.f; }
+    const int mi = isf ? ii % dM : ii / dD, di = isf ? ii / dM : ii % dD;
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+        const int mj = isf ? j % dM : j / dD, dj = isf ? j / dM : j % dD;       // (uniform)
+        const float4* row = reinterpret_cast<const float4*>(sh + (j - j0) * KP);
+        float diff[KP];
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) { const float4 v = row[q]; diff[4 * q] = v.x; diff[4 * q + 1] = v.y; diff[4 * q + 2] = v.z; diff[4 * q + 3] = v.w; }
+        float den = 0.f;
+#pragma unroll
+        for (int r = 0; r < KL; ++r) { diff[r] = ca[r] - diff[r]; den = fmaf(diff[r], diff[r], den); }
+        // pairs need m1 != m AND d1 != d (:724); coinciding kernels give 0 * inf = NaN like the reference's 0 / 0
+        const float wgt = (mj != mi && dj != di) ? __builtin_amdgcn_rcpf(den) : 0.f;
+        if (mj != mi && dj != di) {
+#pragma unroll
+            for (int r = 0; r < KL; ++r) acc[r] = fmaf(diff[r], wgt, acc[r]);
+        }
+    }
+    if (i >= np) return;
+    float* dst = part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * np + i) * KL;
+#pragma unroll
+    for (int r = 0; r < KL; ++r) dst[r] = acc[r];
+}
+
+// chunk partials -> cd | fd (each in its tensor's own layout), and the bias terms bd[m] = sum_{m1 != m} 1/(b[m]-b[m1]), pd likewise
+__global__ __launch_bounds__(256) void gdiff_finish_kernel(const float* __restrict__ part, const float* __restrict__ b, const float* __restrict__ p,
+                                                           float* __restrict__ cd, float* __restrict__ fd, float* __restrict__ bd, float* __restrict__ pd,
+                                                           int dM, int dD, int kl, int nchunks)
+{
+    const long n = (long)dM * dD * kl;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < 2 * n) {
+        const int z = idx >= n;
+        const long e = idx - z * n;
+        float s = 0.f;
+        for (int y = 0; y < nchunks; ++y) s += part[((long)z * nchunks + y) * n + e];
+        (z ? fd : cd)[e] = s;
+        return;
+    }
+    const long t = idx - 2 * n;
+    if (t < dM) {
+        float s = 0.f;
+        for (int m1 = 0; m1 < dM; ++m1) if (m1 != (int)t) s += 1.f / (b[t] - b[m1]);
+        bd[t] = s;
+    } else if (t < dM + dD) {
+        const int d = (int)t - dM;
+        float s = 0.f;
+        for (int d1 = 0; d1 < dD; ++d1) if (d1 != d) s += 1.f / (p[d] - p[d1]);
+        pd[d] = s;
+    }
+}
+
+// Other supports (non-square, or not 3x3 / 5x5 / 7x7): the distance matrix den[(m,d)][(m1,d1)] once per kernel pair (2 (dM dD)^2 floats), then one
+// thread per (m,d,k,l) over the partners in the reference's (m1,d1) order.
 __global__ __launch_bounds__(256) void kdist_kernel(const float* __restrict__ c, const float* __restrict__ f,
                                                     float* __restrict__ den, int dM, int dD, int kl)
 {
@@ -157,15 +236,48 @@ __global__ __launch_bounds__(256) void gradient_diff_kernel(const float* __restr
     if (m == 0 && r == 0) pd[d] = sp;
 }
 
+// partner chunk and chunk count of the launch for dM*dD kernels
+static void gdiff_geom(long np, int* chunk, int* nchunks)
+{
+    int ch = 128;
+    while ((np + ch - 1) / ch > 32) ch *= 2;
+    *chunk = ch; *nchunks = (int)((np + ch - 1) / ch);
+}
+
+size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl)
+{
+    const long np = (long)dM * dD;
+    int chunk, nchunks;
+    gdiff_geom(np, &chunk, &nchunks);
+    const int kl = Nk * Nl;
+    if (kl != 9 && kl != 25 && kl != 49) return (size_t)2 * np * np;      // (the generic kernels' distance matrix)
+    return (size_t)2 * nchunks * np * kl;
+}
+
 hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
-                                float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st)
+                                float* bd, float* pd, float* part_ws, int dM, int dD, int Nk, int Nl, hipStream_t st)
 {
     const long np = (long)dM * dD;
     const int kl = Nk * Nl;
-    kdist_kernel<<<dim3((unsigned)((np * np + 255) / 256)), 256, 0, st>>>(c, f, den_ws, dM, dD, kl);
+    if (kl != 9 && kl != 25 && kl != 49) {
+        kdist_kernel<<<dim3((unsigned)((np * np + 255) / 256)), 256, 0, st>>>(c, f, part_ws, dM, dD, kl);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        gradient_diff_kernel<<<dim3((unsigned)((np * kl + 255) / 256)), 256, 0, st>>>(c, f, b, p, part_ws, cd, fd, bd, pd, dM, dD, Nk, Nl);
+        return hipGetLastError();
+    }
+    int chunk, nchunks;
+    gdiff_geom(np, &chunk, &nchunks);
+    const dim3 grid((unsigned)((np + 255) / 256), (unsigned)nchunks, 2);
+    const size_t lds = sizeof(float) * (size_t)chunk * ((kl + 3) & ~3);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (kl == 9) gdiff_part_kernel<9><<<grid, 256, lds, st>>>(c, f, part_ws, dM, dD, chunk);
+    else if (kl == 25) gdiff_part_kernel<25><<<grid, 256, lds, st>>>(c, f, part_ws, dM, dD, chunk);
+    else gdiff_part_kernel<49><<<grid, 256, lds, st>>>(c, f, part_ws, dM, dD, chunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    gradient_diff_kernel<<<dim3((unsigned)((np * kl + 255) / 256)), 256, 0, st>>>(c, f, b, p, den_ws, cd, fd, bd, pd, dM, dD, Nk, Nl);
+    const long total = 2 * np * kl + dM + dD;
+    gdiff_finish_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(part_ws, b, p, cd, fd, bd, pd, dM, dD, kl, nchunks);
     return hipGetLastError();
 }
 

@@ -84,13 +84,20 @@ class DataParallelStep:
         self.net.step_grad(frames, recon)
         # the collective is enqueued on the library's own stream: gradients -> all-reduce -> update stay ordered
         # without any host synchronisation
-        with torch.cuda.stream(st):
-            if ev: ev[1].record(st)
-            scale = allreduce_sum_(self.gbuf, self.group)
-            if ev: ev[2].record(st)
-            # the tail now holds the sum over ranks of the previous step's post-update MSEs: keep the global mean before
-            # aefft_net_step_apply overwrites the tail with this step's local values
-            self._mse_prev = self.gbuf[self.tail] * scale
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            with torch.cuda.stream(st):
+                if ev: ev[1].record(st)
+                scale = allreduce_sum_(self.gbuf, self.group)
+                if ev: ev[2].record(st)
+                # the tail now holds the sum over ranks of the previous step's post-update MSEs: keep the global mean before
+                # aefft_net_step_apply overwrites the tail with this step's local values
+                self._mse_prev = self.gbuf[self.tail] * scale
+        else:
+            # no process group: nothing is enqueued between the two halves (a kernel there -- even the 4-float copy of the tail --
+            # is a launch on the step's critical path); the step's own MSEs are the global ones (`mse` of aefft_net_step_apply)
+            scale = 1.0
+            if ev: ev[1].record(st); ev[2].record(st)
         self._scale = scale
         self.net.step_apply(del0, maxdiff, sym, scale, mse)
         if ev:
@@ -98,7 +105,8 @@ class DataParallelStep:
             self.timers.append(ev)
 
     def mse_tail(self):
-        """global-batch post-update MSE per pair of the step BEFORE the last one (it travelled in the last gradient all-reduce); None before the second step"""
+        """global-batch post-update MSE per pair of the step BEFORE the last one (it travelled in the last gradient all-reduce); None before the
+        second step and without a process group (the `mse` output of the step is then already global)"""
         return self._mse_prev
 
     def flush_mse(self):

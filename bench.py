@@ -40,20 +40,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # kernel id (aefft_prof_name) -> kernel family in the rocprofv3 --pmc summaries under profiles/
-KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction)", "r2c_rows": "r2c_rows_kernel<512> (input transform, row pass)",
-                "c2r_rows": "c2r_rows_kernel<512> (reconstruction, row pass)", "r2c_cols": "fwd_cols_kernel<512,16> (input transform, column pass + crop)",
-                "kgrad": "kgrad_group_kernel<9,9> (pruned inverse transform of S)", "opmse": "opmse_kernel (post-update MSE, operator form)",
-                "chain": "chain_kernel (network on the basis frames + batch moments)", "kspec": "kspec_group_kernel (kernel spectra from the taps)"}
+KERNEL_NAMES = {"contract": "contract_mfma_kernel<*> (per-bin channel contraction)", "r2c_rows": "r2c_rows_kernel<N> (input transform, row pass)",
+                "c2r_rows": "c2r_rows_kernel<N> (reconstruction, row pass)", "r2c_cols": "fwd_cols_kernel<N,CW> (input transform, column pass + crop)",
+                "c2r_cols": "inv_cols_kernel<N,CW> (reconstruction, column pass, operator expansion on load)",
+                "kgrad": "kgrad_group_kernel<9,9> (pruned inverse transform of S)", "opmse": "tail_kernel (post-update MSE through G' + the next step's operator chain)",
+                "chain": "chain_kernel (network on the basis frames)", "kspec": "kspec_group_kernel (G' / compact spectra / bin-major record from the taps)",
+                "sgrad": "msgrad_kernel (batch moments + S of every pair)", "weight_taps": "wgrad_taps_kernel (g_c, g_f from Q in coordinate space)",
+                "update": "update_group_kernel (clipped-momentum update, tied / multiobjective terms)", "gradient_diff": "gradient_diff kernels (multiobjective term)"}
 PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "contract_kernel", "contract_group_kernel"], "r2c_rows": ["r2c_rows_kernel"],
               "r2c_cols": ["fwd_cols_kernel"], "c2r_cols": ["inv_cols_kernel"], "c2r_rows": ["c2r_rows_kernel"],
               "kgrad": ["kgrad_kernel", "kgrad_group_kernel"], "kspec": ["kspec_kernel", "kspec_group_kernel"], "diff_mse": ["diff_mse_kernel"],
-              "opmse": ["opmse_kernel"], "chain": ["chain_kernel"], "sgrad": ["sgrad_kernel"], "moment": ["moment_kernel"], "weight_taps": ["wgrad_taps_kernel"]}
+              "opmse": ["opmse_kernel", "tail_kernel"], "chain": ["chain_kernel"], "sgrad": ["sgrad_kernel", "msgrad_kernel"], "moment": ["moment_kernel"], "weight_taps": ["wgrad_taps_kernel"]}
 
 
 def pmc_traffic(variant, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note; tools/pmc.py).  None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg3{variant}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_cfg3{variant}.json")
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -64,11 +67,23 @@ def pmc_traffic(variant, kernel):
     return b / n if n else None
 
 
+def finite_json(o):
+    """JSON has no NaN / Infinity: a non-finite number is printed as a string (and flagged by the mse_finite fields)."""
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return str(o)
+    if isinstance(o, dict):
+        return {k: finite_json(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [finite_json(v) for v in o]
+    return o
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preheat", type=int, default=300, help="untimed steps in front of the warm-up steps (clock ramp of the chip)")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (weak scaling)")
     ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
     ap.add_argument("--size", type=int, default=512)
@@ -139,64 +154,56 @@ def cpu_baseline(N, scale, maps=(8, 16, 32, 64), D=3, Nk=5):
                                        "method": "EXTRAPOLATED, not timed: pair-1 time x iteration-count ratio of the backprop loop nest"}}
 
 
-def variant_p1(aefft, torch, np, ctx, steps=4):
-    """cfg3-P1 (no pooling: every pair at 512^2, 5.7 GB of kernel spectra -- honestly HBM-sized): a short timed run."""
-    N, D, maps, Nk, B = 512, 3, [8, 16, 32, 64], 5, 32
-    net = aefft.Net(ctx, D, N, N, maps, Nk, 1, batch=B)
-    init_weights(net, np)
-    dev = f"cuda:{ctx.device}"
-    frames = synth_frames(torch, B, D, N, dev, first_index=0)
-    recon = torch.empty_like(frames)
-    mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
-    for _ in range(2):
-        net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
-    ctx.sync(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
-    ctx.sync(); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    ctx.prof_enable(True)
-    net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)     # (first launches of the profiled pass's own kernels: excluded)
-    ctx.sync(); ctx.prof_reset()
-    net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
-    prof = ctx.prof_read(); ctx.prof_enable(False)
-    ok = bool(np.isfinite(mse.cpu().numpy()).all())
-    net.close()
-    del frames, recon
-    torch.cuda.empty_cache()
-    step_bytes = sum(v["bytes"] for v in prof.values())
-    name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-    return {"workload": "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512)", "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
-            "mse_finite": ok, "step_algo_GB": step_bytes / 1e9, "step_frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
-            "dominant_kernel": {"name": name, "ms": dom["ms"], "GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] else 0.0}}
-
-
-def variant_per_frame(aefft, torch, np, ctx, steps=20):
-    """The headline workload in the PER-FRAME form (development switch NOOPFORM: every layer evaluated for every frame, round 1's
-    step) -- reported beside the operator form so that the gain of contracting the batch first is visible, not assumed."""
-    N, D, maps, Nk, B = 512, 3, [8, 16, 32, 64], 5, 32
-    ctx.set_flags("NOOPFORM")
+def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2, sym=0, maxdiff=0, flags=(), del0=0.2):
+    """A short timed run of one BASELINE config through the same step the headline uses, with its own HIP-event profile:
+    frames/s, algorithmic bytes of the kernel groups as launched, whole-step fraction of the HBM peak, the dominant
+    kernel's roofline object, and the first / last per-pair post-update MSE of the run (a non-finite value is FLAGGED, the
+    measurement stands: with del0 = 0.2 and U(-3,3) weights the trajectory is in the reference's own unstable regime)."""
+    D, Nk = 3, 5
+    ctx.set_flags(*flags)
     try:
-        net = aefft.Net(ctx, D, N, N, maps, Nk, 2, batch=B)
+        net = aefft.Net(ctx, D, N, N, list(maps), Nk, scale, batch=B)
+        form = net.step_form()
         init_weights(net, np)
         dev = f"cuda:{ctx.device}"
         frames = synth_frames(torch, B, D, N, dev, first_index=0)
         recon = torch.empty_like(frames)
         mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
-        for _ in range(5):
-            net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+
+        def step():
+            net.step_grad(frames, recon); net.step_apply(del0, maxdiff, sym, 1.0, mse)
+
+        step(); ctx.sync()
+        mse_first = mse.cpu().numpy().tolist()
+        for _ in range(max(warmup - 1, 0)):
+            step()
         ctx.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            net.step_grad(frames, recon); net.step_apply(0.2, 0, 0, 1.0, mse)
+            step()
         ctx.sync(); torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        mse_host = mse.cpu().numpy().tolist()
+        mse_last = mse.cpu().numpy().tolist()
+        ctx.prof_enable(True)
+        step()                                  # (first launches of the profiled pass's own kernels: excluded)
+        ctx.sync(); ctx.prof_reset()
+        for _ in range(2):
+            step()
+        prof = ctx.prof_read(); ctx.prof_enable(False)
         net.close()
+        del frames, recon
+        torch.cuda.empty_cache()
     finally:
         ctx.set_flags()
-    return {"workload": "cfg3-P2, per-frame form (NOOPFORM)", "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps, "mse_per_pair": mse_host}
+    step_bytes = sum(v["bytes"] for v in prof.values()) / 2
+    name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_s = dom["ms"] / dom["launches"] * 1e-3
+    ach = dom["bytes"] / dom["launches"] / avg_s / 1e9 if avg_s else 0.0
+    return {"workload": label, "step_form": form, "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps, "mse_first": mse_first, "mse_last": mse_last,
+            "mse_finite": bool(np.isfinite(mse_last).all()), "step_algo_GB": step_bytes / 1e9, "step_frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(name, name), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_bytes_per_launch": dom["bytes"] / dom["launches"],
+                         "share_of_kernel_time": dom["ms"] / sum(v["ms"] for v in prof.values()), "traffic": None}}
 
 
 def variant_spatial(aefft, torch, np, ctx, steps=5):
@@ -304,8 +311,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    # Pre-heat: a FIXED amount of untimed work of the same kind in front of the W warm-up steps.  Measured (tools/steptimes.py): after
+    # idling through the set-up the chip takes ~10 ms of sustained load to reach its steady clocks -- the first 40 steps run 4-6 % slow --
+    # and a 20-step timed region (3.5 ms) would be measuring that ramp, not the step.
+    mse_first = None
+    for i in range(a.preheat + a.warmup):      # (the last a.warmup of them are the contract's W warm-up steps)
         step()
+        if i == 0:
+            ctx.sync(); mse_first = mse.cpu().numpy().tolist()      # post-update MSE of the very first step (untimed)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -318,8 +331,7 @@ def main():
         dt = float(t.item())
     ctx.sync()
     mse_host = mse.cpu().numpy().tolist()
-    if not all(np.isfinite(mse_host)):
-        raise SystemExit(f"non-finite MSE {mse_host}")
+    mse_finite = bool(np.isfinite(mse_host).all())      # flagged in the JSON line, the timing stands (del0 = 0.2 on U(-3,3) weights is the reference's unstable regime)
 
     roof = None
     if rank == 0 and not a.no_roofline:
@@ -357,18 +369,27 @@ def main():
         net.close()
         del frames, recon
         torch.cuda.empty_cache()
-        variants = {"per_frame_form": variant_per_frame(aefft, torch, np, ctx), "p1": variant_p1(aefft, torch, np, ctx),
-                    "spatial": variant_spatial(aefft, torch, np, ctx)}
+        M4, M3, M5 = [8, 16, 32, 64], [8, 16, 32], [8, 16, 32, 64, 128]
+        variants = {
+            "per_frame_form": fft_variant(aefft, torch, np, ctx, "cfg3-P2, per-frame form (NOOPFORM: every layer for every frame, round 1's step)",
+                                          512, M4, 2, 32, steps=20, warmup=5, flags=("NOOPFORM",)),
+            "p1": fft_variant(aefft, torch, np, ctx, "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512; 5.7 GB of kernel spectra)",
+                              512, M4, 1, 32, steps=10, warmup=2),
+            "cfg2": fft_variant(aefft, torch, np, ctx, "cfg2: 256x256x3, 3 pairs 3->8->16->32, 5x5, pool 2/layer, B = 1 (BASELINE configs[1])",
+                                256, M3, 2, 1, steps=50, warmup=5),
+            "cfg5": fft_variant(aefft, torch, np, ctx, "cfg5 per-GPU shape: 1024x1024x3, 5 pairs 3->8->...->128, 5x5, pool 2/layer, tied weights + "
+                                "multiobjective (sym=1, maxdiff=1), 32 frames (BASELINE configs[4])", 1024, M5, 2, 32, steps=10, warmup=2, sym=1, maxdiff=1),
+            "spatial": variant_spatial(aefft, torch, np, ctx)}
 
     if rank == 0:
         out = {
             "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": world * B * a.steps / dt, "unit": "frames/s",
-            "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup, "preheat_steps": a.preheat, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3-{a.variant.upper()}: {N}x{N}x3 frames, 4 pairs 3->8->16->32->64, 5x5, pool {s}/layer, FFT mode, "
                                    f"fwd + 1 loop-body iteration per pair ({'per-frame form' if 'NOOPFORM' in a.flags else 'operator form'})", "frames_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of packed kernel-support gradients)" if world > 1 else "")},
-            "mse_per_pair": mse_host,
+            "mse_per_pair": mse_host, "mse_first_step": mse_first, "mse_finite": mse_finite,
         }
         if roof:
             out["roofline"] = roof
@@ -376,7 +397,7 @@ def main():
             out["cpu_baseline"] = cpu
         if variants:
             out["variants"] = variants
-        print(json.dumps(out), flush=True)
+        print(json.dumps(finite_json(out)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
