@@ -945,6 +945,7 @@ struct aefft_net {
     size_t scratch_n = 0;
     float* mse_pre = nullptr;  // = scratch
     float* mse_post = nullptr; // = scratch + L
+    float *gd_out = nullptr, *gd_part = nullptr;   // multiobjective mode: [cd | fd | bd | pd] per pair, and the chunk partial sums (gradient_diff_ws_floats)
     float* mse_slots = nullptr; // [L][MSE_SLOTS*MSE_SLOT_STRIDE] accumulators of the fused re-forward MSE (zero between uses)
     float* mse_dev = nullptr;  // scratch for bursts
     size_t mse_cap = 0;
@@ -1984,10 +1985,38 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
     bool fused_upd = false;                                                // the tap half of the update rides in the tail launch (below)
     bool gp_route = false;                                                 // the spectra launch wrote G' = F'.C'/(dM dD) for every pair but the innermost
     UpdateGroup wupd{};
-    bool grouped_w = !maxdiff && n->L > 1 && n->L <= 8 && !nogroup1;     // the multiobjective terms need per-pair workspaces
+    bool grouped_w = n->L > 1 && n->L <= 8 && !nogroup1;
     for (int l = 0; l < n->L && grouped_w; ++l) {
         const Pair& q = n->pr[l];
         grouped_w = q.Nk == n->pr[0].Nk && q.Nl == n->pr[0].Nl && pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny);
+    }
+    // multiobjective terms (fft_backproplib.cu:709-753) of every pair in one grouped launch; their outputs and the chunk partial sums
+    // live in per-net buffers (allocated the first time maxdiff is asked for)
+    GdiffGroup gd{};
+    if (grouped_w && maxdiff) {
+        const int kl = n->pr[0].Nk * n->pr[0].Nl;
+        grouped_w = kl == 9 || kl == 25 || kl == 49;
+        if (grouped_w && !n->gd_out) {
+            size_t no = 0, np_ = 0;
+            for (const Pair& q : n->pr) { no += 2 * (size_t)q.dM * q.dD * kl + q.dM + q.dD; np_ += gradient_diff_ws_floats(q.dM, q.dD, q.Nk, q.Nl); }
+            RET_IF(net_alloc_t(n, &n->gd_out, no));
+            RET_IF(net_alloc_t(n, &n->gd_part, np_));
+        }
+        if (grouped_w) {
+            float *o = n->gd_out, *pw = n->gd_part;
+            double gbytes = 0;
+            for (int l = 0; l < n->L; ++l) {
+                Pair& q = n->pr[l];
+                const size_t nk = (size_t)q.dM * q.dD * kl;
+                gd.q[l] = GdiffProb{q.c, q.f, q.b, q.p, o, o + nk, o + 2 * nk, o + 2 * nk + q.dM, pw, q.dM, q.dD, 0, 0};
+                o += 2 * nk + q.dM + q.dD; pw += gradient_diff_ws_floats(q.dM, q.dD, q.Nk, q.Nl);
+                gbytes += (double)nk * 16.0;
+            }
+            gd.n = n->L;
+            Bracket br(ctx, KID_GDIFF, gbytes);
+            hipError_t e = launch_gradient_diff_group(gd, n->pr[0].Nk, n->pr[0].Nl, ctx->cur);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "gradient_diff(group)", e);
+        }
     }
     if (grouped_w) {
         UpdateGroup ug{};
@@ -1999,6 +2028,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
             ug.a[l] = mk_update(q.c, q.f, q.b, q.p, g, g + nk, g + 2 * nk, g + 2 * nk + q.dM, Momentum{q.Dc, q.Df, q.Db, q.Dp},
                                 q.dM, q.dD, q.Nk, q.Nl, del, sym, gscale, n->mse_post + l);
+            if (maxdiff) { ug.a[l].cd = gd.q[l].cd; ug.a[l].fd = gd.q[l].fd; ug.a[l].bd = gd.q[l].bd; ug.a[l].pd = gd.q[l].pd; }
             ubytes += (double)nk * 4.0 * 8;
         }
         ug.n = n->L;
@@ -2006,7 +2036,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         // Fused update (operator form, plain gradients): no update launch.  The spectra launch reads every tap THROUGH the pending
         // update (w - clip_step(g, D): TapUpd) and carries the bias half as a trailing workgroup per pair; the taps and their momentum
         // are stored in place by trailing workgroups of the tail launch (tail_kernel) -- nothing in between reads them.
-        fused_upd = ride && !sym && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
+        fused_upd = ride && !sym && !maxdiff && !flag(AEFFT_F_NOFUSEUPD) && !ctx->prof;
         // Operator form with the chain launch: NO planar spectra are written.  The next step's chain reads the bin-major record Wp
         // and the compact planes Cc_l (C_l where the next pair's grid lands); the post-update MSE reads G'_l = F'_l.C'_l/(dM dD) --
         // dD*dD planes per pair, the spectrum of the (2Nk-1)^2 kernel f' (*) c' whose taps the transforming workgroups form

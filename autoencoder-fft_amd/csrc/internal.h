@@ -225,6 +225,10 @@ size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl);      // floats o
 hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, const float* p, float* cd, float* fd,
                                 float* bd, float* pd, float* den_ws, int dM, int dD, int Nk, int Nl, hipStream_t st);   // fft.cu:709
 
+struct GdiffProb { const float *c, *f, *b, *p; float *cd, *fd, *bd, *pd, *part; int dM, dD; int chunk, nchunks; /* (filled by the launcher) */ };
+struct GdiffGroup { GdiffProb q[8]; int n; int start[9], fstart[9]; };
+hipError_t launch_gradient_diff_group(GdiffGroup& g, int Nk, int Nl, hipStream_t st);                 // every pair's fft.cu:709 terms, two launches
+
 // ---- spatial_kernels.hip ---------------------------------------------------------------
 hipError_t launch_conv_spatial(const float* in, float* out, const float* c, const float* b, int B, int dD, int dM,
                                int Nx, int Ny, int Nk, int Nl, int ak, int al, float in_scale_div, int lo, hipStream_t st,

@@ -5,6 +5,7 @@
 // These tensors are tiny (dM*dD*Nk*Nl floats); the kernels are launch-latency bound.
 #include "internal.h"
 #include "update_device.h"
+#include <algorithm>
 
 namespace aefft {
 
@@ -109,17 +110,17 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
 // replicas of a data-parallel run must stay bit-identical).  No (dM dD)^2 distance matrix is stored (537 MB at cfg5's 64->128 pair).
 // ------------------------------------------------------------------------------------------
 template <int KL>
-__global__ __launch_bounds__(256) void gdiff_part_kernel(const float* __restrict__ c, const float* __restrict__ f, float* __restrict__ part,
-                                                         int dM, int dD, int chunk)
+__device__ __forceinline__ void gdiff_part_body(const float* __restrict__ c, const float* __restrict__ f, float* __restrict__ part,
+                                                int dM, int dD, int chunk, int bx, int by, int bz, int nchunks)
 {
     constexpr int KP = (KL + 3) & ~3;                      // LDS row pitch: whole float4s
     extern __shared__ float4 gd_sh4[];
     float* sh = reinterpret_cast<float*>(gd_sh4);
     const int np = dM * dD;
-    const bool isf = blockIdx.z != 0;                      // rows of f are (d,m)-ordered, rows of c (m,d)-ordered
+    const bool isf = bz != 0;                              // rows of f are (d,m)-ordered, rows of c (m,d)-ordered
     const float* __restrict__ w = isf ? f : c;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * chunk, j1 = min(np, j0 + chunk);
+    const int i = bx * 256 + threadIdx.x;
+    const int j0 = by * chunk, j1 = min(np, j0 + chunk);
     // partner taps -> LDS (coalesced), zero padding of the pitch
     for (int t = threadIdx.x; t < (j1 - j0) * KP; t += 256) {
         const int j = t / KP, r = t - j * KP;
@@ -148,18 +149,40 @@ __global__ __launch_bounds__(256) void gdiff_part_kernel(const float* __restrict
         }
     }
     if (i >= np) return;
-    float* dst = part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * np + i) * KL;
+    float* dst = part + (((long)bz * nchunks + by) * np + i) * KL;
 #pragma unroll
     for (int r = 0; r < KL; ++r) dst[r] = acc[r];
 }
 
+template <int KL>
+__global__ __launch_bounds__(256) void gdiff_part_kernel(const float* __restrict__ c, const float* __restrict__ f, float* __restrict__ part,
+                                                         int dM, int dD, int chunk)
+{
+    gdiff_part_body<KL>(c, f, part, dM, dD, chunk, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+// every pair's partial sums in one launch (the small pairs fill the chip beside the large one): workgroup -> (pair, tensor, chunk, row tile)
+template <int KL>
+__global__ __launch_bounds__(256) void gdiff_part_group_kernel(const GdiffGroup g)
+{
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const GdiffProb& q = g.q[p];
+    int blk = blockIdx.x - g.start[p];
+    const int rt = (q.dM * q.dD + 255) / 256;
+    const int bx = blk % rt; blk /= rt;
+    const int by = blk % q.nchunks, bz = blk / q.nchunks;
+    gdiff_part_body<KL>(q.c, q.f, q.part, q.dM, q.dD, q.chunk, bx, by, bz, q.nchunks);
+}
+
 // chunk partials -> cd | fd (each in its tensor's own layout), and the bias terms bd[m] = sum_{m1 != m} 1/(b[m]-b[m1]), pd likewise
-__global__ __launch_bounds__(256) void gdiff_finish_kernel(const float* __restrict__ part, const float* __restrict__ b, const float* __restrict__ p,
-                                                           float* __restrict__ cd, float* __restrict__ fd, float* __restrict__ bd, float* __restrict__ pd,
-                                                           int dM, int dD, int kl, int nchunks)
+__device__ __forceinline__ void gdiff_finish_body(const float* __restrict__ part, const float* __restrict__ b, const float* __restrict__ p,
+                                                  float* __restrict__ cd, float* __restrict__ fd, float* __restrict__ bd, float* __restrict__ pd,
+                                                  int dM, int dD, int kl, int nchunks, long blk)
 {
     const long n = (long)dM * dD * kl;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = blk * 256 + threadIdx.x;
     if (idx < 2 * n) {
         const int z = idx >= n;
         const long e = idx - z * n;
@@ -179,6 +202,22 @@ __global__ __launch_bounds__(256) void gdiff_finish_kernel(const float* __restri
         for (int d1 = 0; d1 < dD; ++d1) if (d1 != d) s += 1.f / (p[d] - p[d1]);
         pd[d] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void gdiff_finish_kernel(const float* __restrict__ part, const float* __restrict__ b, const float* __restrict__ p,
+                                                           float* __restrict__ cd, float* __restrict__ fd, float* __restrict__ bd, float* __restrict__ pd,
+                                                           int dM, int dD, int kl, int nchunks)
+{
+    gdiff_finish_body(part, b, p, cd, fd, bd, pd, dM, dD, kl, nchunks, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void gdiff_finish_group_kernel(const GdiffGroup g, int kl)
+{
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.fstart[i]) p = i;
+    const GdiffProb& q = g.q[p];
+    gdiff_finish_body(q.part, q.b, q.p, q.cd, q.fd, q.bd, q.pd, q.dM, q.dD, kl, q.nchunks, (long)blockIdx.x - g.fstart[p]);
 }
 
 // Other supports (non-square, or not 3x3 / 5x5 / 7x7): the distance matrix den[(m,d)][(m1,d1)] once per kernel pair (2 (dM dD)^2 floats), then one
@@ -278,6 +317,32 @@ hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, 
     if (e != hipSuccess) return e;
     const long total = 2 * np * kl + dM + dD;
     gdiff_finish_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(part_ws, b, p, cd, fd, bd, pd, dM, dD, kl, nchunks);
+    return hipGetLastError();
+}
+
+// gradient_diff of up to 8 pairs with the same 3x3 / 5x5 / 7x7 support in two launches (GdiffProb::part: gradient_diff_ws_floats each)
+hipError_t launch_gradient_diff_group(GdiffGroup& g, int Nk, int Nl, hipStream_t st)
+{
+    const int kl = Nk * Nl;
+    if (g.n < 1 || g.n > 8 || (kl != 9 && kl != 25 && kl != 49)) return hipErrorInvalidValue;
+    long total = 0, ftotal = 0;
+    size_t lds = 0;
+    for (int i = 0; i < g.n; ++i) {
+        GdiffProb& q = g.q[i];
+        const long np = (long)q.dM * q.dD;
+        gdiff_geom(np, &q.chunk, &q.nchunks);
+        g.start[i] = (int)total; total += ((np + 255) / 256) * q.nchunks * 2;
+        g.fstart[i] = (int)ftotal; ftotal += (2 * np * kl + q.dM + q.dD + 255) / 256;
+        lds = std::max(lds, sizeof(float) * (size_t)q.chunk * ((kl + 3) & ~3));
+    }
+    g.start[g.n] = (int)total; g.fstart[g.n] = (int)ftotal;
+    if (lds > 64 * 1024 || total >= (1L << 31) || ftotal >= (1L << 31)) return hipErrorInvalidValue;
+    if (kl == 9) gdiff_part_group_kernel<9><<<dim3((unsigned)total), 256, lds, st>>>(g);
+    else if (kl == 25) gdiff_part_group_kernel<25><<<dim3((unsigned)total), 256, lds, st>>>(g);
+    else gdiff_part_group_kernel<49><<<dim3((unsigned)total), 256, lds, st>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    gdiff_finish_group_kernel<<<dim3((unsigned)ftotal), 256, 0, st>>>(g, kl);
     return hipGetLastError();
 }
 
