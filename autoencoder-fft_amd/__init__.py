@@ -22,7 +22,7 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 # include/aefft.h AEFFT_F_* (development switches; tests/test_abi.py checks this table against the header)
 FLAGS = {n: 1 << i for i, n in enumerate(
     ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
-     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD"])}
+     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD", "NORCORR"])}
 
 
 class AefftError(RuntimeError):
@@ -451,6 +451,18 @@ class Net:
             holder = type("_Raw", (), {"__cuda_array_interface__": iface})()
             self._gradview = (p.value, t.as_tensor(holder, device=f"cuda:{self.ctx.device}"))
         return self._gradview[1]
+
+    def mse_prev_global(self):
+        """torch view of the L floats behind the packed buffer: the global-batch post-update MSE per pair of the step BEFORE the last
+        aefft_net_step_apply (the reduced tail of the last all-reduce times grad_scale, saved by step_apply itself; include/aefft.h)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx.check(self.L.aefft_net_grad_buffer(self.h, C.byref(p), C.byref(n)))
+        t = self.ctx.torch
+        if not hasattr(self, "_prevview") or self._prevview[0] != p.value:
+            iface = {"shape": (self.npairs,), "typestr": "<f4", "data": (p.value + 4 * n.value, False), "version": 2, "strides": None}
+            holder = type("_Raw", (), {"__cuda_array_interface__": iface})()
+            self._prevview = (p.value, t.as_tensor(holder, device=f"cuda:{self.ctx.device}"))
+        return self._prevview[1]
 
     def step_form(self):
         """which form the next training step runs in: "per_frame", "operator" or "operator_chain" (aefft_net_step_form)"""

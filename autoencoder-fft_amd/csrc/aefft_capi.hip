@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}};
 // The switches named by AEFFT_FLAGS stay on for the life of the process: aefft_ctx_set_flags ORs its argument onto them (a test fixture
 // that restores "no flags" does not clear an AEFFT_FLAGS=POISON run).  A name the library does not know is an error, not a silent
 // default run: the first aefft_ctx_create fails with AEFFT_EINVAL and says which.
@@ -852,13 +852,15 @@ extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const f
     const size_t nk = (size_t)dM * dD * Nk * Nl;
     void *ws, *small;
     RET_IF(ws_get(ctx, WS_REAL, sizeof(float) * (size_t)B * dM * Nx * Ny, &ws));
-    RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * (2 * nk + dM + dD), &small));
+    const size_t nrq = spatial_rq_floats(dD, Nk, Nl);
+    RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * (2 * nk + dM + dD + nrq), &small));
     SpatialGradArgs a{};
     a.in = in_d; a.out = out_d; a.hin = hin_d; a.f = f_d;
     a.gc = (float*)small; a.gf = a.gc + nk; a.gb = a.gf + nk; a.gp = a.gb + dM;
     a.ws = (float*)ws;
+    a.rq = a.gp + dD;
     {
-        const size_t pf = spatial_partial_floats(B, dD, dM, Nx, Nk, Nl);
+        const size_t pf = spatial_partial_floats(B, dD, dM, Nx, Ny, Nk, Nl);
         void* part = nullptr;
         if (pf) RET_IF(ws_get(ctx, WS_PART, sizeof(float) * pf, &part));
         a.part = (float*)part;
@@ -1057,7 +1059,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
             (rc = ws_get(ctx, WS_SMALL, sizeof(float) * maxSmall, &dummy)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->real, n->pruned ? 64 : maxReal)) == AEFFT_OK &&
             (rc = net_alloc_t(n, &n->mse_slots, (size_t)n->L * MSE_SLOTS * MSE_SLOT_STRIDE)) == AEFFT_OK &&
-            (rc = net_alloc_t(n, &n->grad, goff + (size_t)n->L)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
+            (rc = net_alloc_t(n, &n->grad, goff + 2 * (size_t)n->L)) == AEFFT_OK && (rc = net_alloc_t(n, &n->scratch, soff)) == AEFFT_OK) {
             n->scratch_n = soff; n->mse_pre = n->scratch; n->mse_post = n->scratch + n->L;
             for (int l = 0; l < n->L; ++l) n->pr[l].es = n->scratch + esoff[l];
             n->grad_n = goff;
@@ -1087,7 +1089,7 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     }
     if (rc != AEFFT_OK) { aefft_net_destroy(n); return rc; }
     hipError_t e = hipMemsetAsync(n->mse_slots, 0, sizeof(float) * n->L * MSE_SLOTS * MSE_SLOT_STRIDE, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(n->grad + n->grad_n, 0, sizeof(float) * n->L, ctx->stream);      // (the MSE tail of the packed buffer: zero before the first step)
+    if (e == hipSuccess) e = hipMemsetAsync(n->grad + n->grad_n, 0, sizeof(float) * 2 * n->L, ctx->stream);      // (the MSE tail of the packed buffer: zero before the first step)
     if (e != hipSuccess) { aefft_net_destroy(n); return fail(ctx, AEFFT_EHIP, "memset(mse slots)", e); }
     for (auto& q : n->pr) {
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
@@ -2179,7 +2181,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         }
         if (ahead) { n->op_set ^= 1; n->chain_valid = true; }
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, n->grad + n->grad_n);
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, n->grad + n->grad_n, gscale);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
         return AEFFT_OK;
     }
@@ -2236,7 +2238,7 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
         Pair& ql = n->pr[n->L - 1];
         BetaArgs ba{ql.beta, ql.F, ql.b, ql.p, ql.dM, ql.dD, ql.P};
         const bool want_beta = g_in_S[n->L - 1] && ql.beta && ql.dD <= 256;
-        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, want_beta ? &ba : nullptr, n->grad + n->grad_n);     // also the copy-out to mse_d and to the packed buffer's tail
+        hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, want_beta ? &ba : nullptr, n->grad + n->grad_n, gscale);     // also the copy-out to mse_d and to the packed buffer's tail
         ql.G_valid = want_beta && e == hipSuccess;
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
     }

@@ -75,7 +75,8 @@ struct Contract {
 enum { MSE_SLOTS = 256, MSE_SLOT_STRIDE = 16 };
 struct BetaArgs { float* beta; const float2* F; const float *b, *p; int dM, dD; long P; };     // beta == null: off
 hipError_t launch_mse_finish(float* slots /*[L][MSE_SLOTS*MSE_SLOT_STRIDE]*/, float* out /*[L], accumulated*/, float* copy /*[L] nullable*/, int L, hipStream_t st,
-                             const BetaArgs* beta = nullptr, float* copy2 = nullptr /*[L] nullable: a second copy (the tail of the packed gradient buffer)*/);
+                             const BetaArgs* beta = nullptr, float* copy2 = nullptr /*[2L] nullable: the tail of the packed gradient buffer -- [l] <- out[l] after [L + l] <- [l] * prev_scale*/,
+                             float prev_scale = 1.0f);
 struct Contract2 { Contract q[2]; int n; };   // up to two independent contractions in one launch (grid.z is split)
 hipError_t launch_contract2(const Contract2& qq, hipStream_t st);
 // Up to 8 independent contractions of one class in ONE launch (the four pairs' S / dc,df / re-forward convs):
@@ -238,6 +239,7 @@ struct SpatialGradArgs {
     float *gc, *gf, *gb, *gp;             // [dM][dD][Nk][Nl], [dD][dM][Nk][Nl], [dM], [dD]
     float *ws;                            // workspace: dM*Nx*Ny (back-conv) floats
     float *part;                          // workspace: spatial_partial_floats() floats (tiled weight-gradient partial sums); null: naive kernels
+    float *rq;                            // workspace: spatial_rq_floats() floats (the error-input correlation R and its row sums); null: dC through the back-convolved error
     int B, dD, dM, Nx, Ny, Nk, Nl, ak, al;
     float Norm;
     int lo;                               // 0: GPU boundary test '>=0' (backproplib.cu:95), 1: CPU test '>0' (netlib.cpp:344)
@@ -245,7 +247,8 @@ struct SpatialGradArgs {
 };
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st);
 hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st);   // B-11: gf and gb as the CUDA source computes them (after launch_spatial_grad)
-size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl);
+size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl);
+size_t spatial_rq_floats(int dD, int Nk, int Nl);
 hipError_t launch_pool_spatial(const float* in, float* out, long planes, int Nxi, int Nyi, int Nxo, int Nyo, int scale, hipStream_t st);   // netlib.cpp:114   // 0: shape not served by the tiled kernels
 
 }  // namespace aefft

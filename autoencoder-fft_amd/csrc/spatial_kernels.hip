@@ -614,9 +614,13 @@ struct MCorrArgs {
     int ones_row, ones_col;                 // append a row / a column of ones
     int row0, col0;                         // first GEMM row / column of this launch's tile (multiples of 64 / 32*NCB)
     float* part;                            // [B * bands][64][32*NCB]
+    // rowKK > 0: the nA rows are MASKED COPIES of nA / rowKK planes of A -- row (plane, k1, l1) is the plane where the pixel shifted back by
+    // the tap, (i - (rik0 + k1), j - (ril0 + l1)), lies in [rlo, N), zero elsewhere (the error through which a back-convolution tap
+    // reaches an existing hidden pixel: R of launch_spatial_grad)
+    int rowKK, rNK, rik0, ril0, rlo;
 };
 
-template <int NK, int NCB>
+template <int NK, int NCB, int NRB>
 __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
 {
     constexpr int KK = NK * NK, CR = 2, CC = 64, CPX = CR * CC, PA = CPX + 4;          // chunk: 2 rows x 64 columns; A tile pitch (16-byte rows)
@@ -651,13 +655,26 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
         pmin = c_lo / KK; pmax = c_hi >= c_lo ? c_hi / KK : pmin;         // (a tile holding only the ones column still makes one pass)
     }
     const int r0s = a.sgn > 0 ? a.ik0 : -(a.ik0 + NK - 1), c0s = a.sgn > 0 ? a.il0 : -(a.il0 + NK - 1);
-    v16f_s acc[2][NCB];
+    v16f_s acc[NRB][NCB];                                             // NRB = 1: at most 32 GEMM rows, one row block of the matrix instruction
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
+    // per staged A row of this thread (fixed over the chunks): its plane and the shift of its window
+    const int nplA = a.rowKK > 0 ? a.nA / a.rowKK : a.nA;
+    int rpl[8], rsi[8], rsj[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int row = (w * 256 + (int)threadIdx.x) / (128 / 4);
+        const int ga = min(a.row0 + row, a.nA - 1);
+        if (a.rowKK > 0) {
+            const int pl = ga / a.rowKK, tap = ga - pl * a.rowKK, k1 = tap / a.rNK;
+            rpl[w] = pl; rsi[w] = a.rik0 + k1; rsj[w] = a.ril0 + (tap - k1 * a.rNK);
+        } else { rpl[w] = ga; rsi[w] = 0; rsj[w] = 0; }
+    }
+    const int lo_rows = a.rowKK > 0 ? a.rlo : a.loA;
     constexpr int BR = 8;                                             // image rows per workgroup (band)
     const int nchunk_c = (a.Ny + CC - 1) / CC, nchunks = (BR / CR) * nchunk_c;
     constexpr int NBL = (TB * TWR * TWC + 255) / 256;
@@ -671,8 +688,8 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
             const int t = w * 256 + threadIdx.x;
             const int row = t / (CPX / 4), q = (t % (CPX / 4)) * 4;              // GEMM row, pixel quad inside the chunk
             const int i = min(i0 + q / CC, a.Nx - 1), j = min(j0 + q % CC, a.Ny - 4);
-            const int ga = min(a.row0 + row, a.nA - 1);
-            av[w] = *reinterpret_cast<const float4*>(a.A + (bb * a.nA + ga) * plane + (long)i * a.Ny + j);
+            if (NRB == 1 && row >= 32) continue;                                 // (uniform per w: 4 rows per 128 threads... rows 32.. are never multiplied)
+            av[w] = *reinterpret_cast<const float4*>(a.A + (bb * nplA + rpl[w]) * plane + (long)i * a.Ny + j);
         }
     };
     auto store_A = [&](int ch, const float4 (&av)[8]) {
@@ -681,6 +698,7 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
         for (int w = 0; w < 8; ++w) {
             const int t = w * 256 + threadIdx.x;
             const int row = t / (CPX / 4), q = (t % (CPX / 4)) * 4;
+            if (NRB == 1 && row >= 32) continue;
             const int i = i0 + q / CC, j = j0 + q % CC;
             const int ga = a.row0 + row;
             const bool ones = a.ones_row && ga == a.nA;
@@ -689,7 +707,8 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool in_img = i < a.Nx && j + e < a.Ny;
-                float x = (ga < a.nA && in_img && i >= a.loA && j + e >= a.loA) ? vv[e] : 0.f;
+                const int si = i - rsi[w], sj = j + e - rsj[w];
+                float x = (ga < a.nA && in_img && si >= lo_rows && si < a.Nx && sj >= lo_rows && sj < a.Ny) ? vv[e] : 0.f;
                 if (ones && in_img) x = 1.f;
                 o[e] = x;
             }
@@ -745,7 +764,7 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
             for (int ks = 0; ks < 16; ++ks) {
                 const int px = 32 * wv + 2 * ks + kq;
                 const int pr = px / CC, pc = px - pr * CC;
-                const float a0 = At[li * PA + px], a1 = At[(32 + li) * PA + px];
+                const float a0 = At[li * PA + px], a1 = NRB > 1 ? At[(32 + li) * PA + px] : 0.f;
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     const int u = cplane[cb] - p0;
@@ -753,7 +772,7 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
                     if (cplane[cb] >= 0) { if (u >= 0 && u < TB) bvv = Bt[u][coff[cb] + pr * TWC + pc]; }
                     else if (p0 == pmin) bvv = cone[cb];                 // the ones column counts once, with the first plane group
                     acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bvv, acc[0][cb], 0, 0, 0);
-                    acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[1][cb], 0, 0, 0);
+                    if (NRB > 1) acc[NRB - 1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[NRB - 1][cb], 0, 0, 0);
                 }
             }
         }
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
         for (int w2 = 0; w2 < 4; ++w2) {
             if (wv == w2) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kq;
@@ -786,7 +805,7 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
             }
             __syncthreads();
         }
-        for (int t = threadIdx.x; t < 64 * 32; t += 256) dst[(long)(t >> 5) * (32 * NCB) + 32 * cb + (t & 31)] = red[(t >> 5) * 33 + (t & 31)];
+        for (int t = threadIdx.x; t < 64 * 32; t += 256) dst[(long)(t >> 5) * (32 * NCB) + 32 * cb + (t & 31)] = (NRB == 1 && t >= 32 * 32) ? 0.f : red[(t >> 5) * 33 + (t & 31)];
         __syncthreads();
     }
 }
@@ -830,9 +849,16 @@ template <int NK> static hipError_t run_mcorr(MCorrArgs a, int B, float* out, in
         for (int cb0 = 0; cb0 < ncb_all; cb0 += 3) {
             const int ncb = std::min(3, ncb_all - cb0);
             a.row0 = row0; a.col0 = 32 * cb0;
-            if (ncb == 1) mcorr_kernel<NK, 1><<<dim3(bands, B), 256, 0, st>>>(a);
-            else if (ncb == 2) mcorr_kernel<NK, 2><<<dim3(bands, B), 256, 0, st>>>(a);
-            else mcorr_kernel<NK, 3><<<dim3(bands, B), 256, 0, st>>>(a);
+            const bool one_rb = nrows - row0 <= 32;                 // a single 32-row block of the matrix instruction covers the rows
+            if (one_rb) {
+                if (ncb == 1) mcorr_kernel<NK, 1, 1><<<dim3(bands, B), 256, 0, st>>>(a);
+                else if (ncb == 2) mcorr_kernel<NK, 2, 1><<<dim3(bands, B), 256, 0, st>>>(a);
+                else mcorr_kernel<NK, 3, 1><<<dim3(bands, B), 256, 0, st>>>(a);
+            } else {
+                if (ncb == 1) mcorr_kernel<NK, 1, 2><<<dim3(bands, B), 256, 0, st>>>(a);
+                else if (ncb == 2) mcorr_kernel<NK, 2, 2><<<dim3(bands, B), 256, 0, st>>>(a);
+                else mcorr_kernel<NK, 3, 2><<<dim3(bands, B), 256, 0, st>>>(a);
+            }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             msum_kernel<<<dim3((64 * 32 * ncb + 3) / 4), 256, 0, st>>>(a.part, bands * B, 32 * ncb, row0, 32 * cb0, a.nA, a.nB * KK, KK, a.nB, transpose, out,
@@ -854,13 +880,14 @@ template <int NK> static size_t wcorr_part_floats(int nA, int nB, int Nx, int B)
     constexpr int TA = WTile<NK>::TA, TB = WTile<NK>::TB;
     return (size_t)B * ((Nx + 15) / 16) * ((nA + TA - 1) / TA) * ((nB + TB - 1) / TB) * (TA * TB * NK * NK + TA);
 }
-size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Nk, int Nl)
+size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl)
 {
     if (!dconv_ok(Nk, Nl, B)) return 0;
     size_t x = 0;
     if (Nk == 3) x = std::max(wcorr_part_floats<3>(dM, dD, Nx, B), wcorr_part_floats<3>(dD, dM, Nx, B));
     else if (Nk == 5) x = std::max(wcorr_part_floats<5>(dM, dD, Nx, B), wcorr_part_floats<5>(dD, dM, Nx, B));
     else x = std::max(wcorr_part_floats<7>(dM, dD, Nx, B), wcorr_part_floats<7>(dD, dM, Nx, B));
+    x = std::max(x, (size_t)B * ((Nx + 7) / 8) * ((Ny + 255) / 256) * (16 * (9 * 25 + 3)));      // rcorr_kernel's workgroup partials (rc_pw<3>)
     return std::max(x, mcorr_part_floats(Nx, B));
 }
 template <int NK> static hipError_t launch_wcorr(const WCorrArgs& a, int B, float* out, float* osum, float scale, hipStream_t st)
@@ -1078,8 +1105,307 @@ hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// dC without the back-convolved error (3x3 supports, dD <= 3 input channels: the reference's default first layer).
+// With s0 = out - in:  g[m][q] = sum_{d1,t1} f[d1][m][t1] s0[d1][q + t1]  and  dC[m][d][t] = sum_q g[m][q] in[d][q - t];  summed over the
+// error pixel p = q + t1 instead,
+//     dC[m][d][t] = sum_{d1,t1} f[d1][m][t1] R_t1[d1][d][t1 + t],      R_t1[d1][d][u] = sum_{p : p - t1 is a hidden pixel} s0[d1][p] in[d][p - u]
+// -- the correlation of the dD error planes with the dD input planes at the (2Nk-1)^2 composite offsets u: dD*dD*25 numbers per mask.
+// "p - t1 is a hidden pixel" only removes border rows / columns of the error (rows 0, 1, Nx-1 at most, for |t1| <= 1 and lo <= 1), so
+// the kernel accumulates the correlation per REGION -- row classes {0, 1, Nx-1, the rest} x column sets {all, 0, 1, Ny-1} -- and the
+// contraction kernel puts each tap's R together from the regions its mask admits.  Neither the dM-plane error g (419 MB written by a
+// back-convolution launch and read back by a 50-row correlation at 32 x 256^2 x 50 maps) nor s0 itself is stored: the step reads `out`
+// and `in` once.  dB[m] = sum_q g[m][q] comes from the regions' sums of s0.
+//
+// rcorr_kernel: workgroup = 8 image rows x 256 columns of one frame; the error tile and the input tile (halo 4) in LDS.  Thread =
+// (input plane d, row offset a) x segment (row, half): 5 column offsets x dD error planes = 15 running sums, one new input element and
+// dD error elements (broadcast among the lanes of a segment) per pixel.
+// ------------------------------------------------------------------------------------------
+struct RCorrArgs { const float *out, *in; float* part; int B, Nx, Ny, ik0, il0, lo; };
+constexpr int RC_TR = 8, RC_CW = 256, RC_T = 5, RC_NSEG = 16;
+template <int D> constexpr int rc_pw() { return 16 * (D * D * RC_T * RC_T + D); }      // floats of one workgroup's partial: [rc 4][cs 4][d1][d][a][b] | [rc][cs][d1]
+
+template <int D>
+__global__ __launch_bounds__(256) void rcorr_kernel(const RCorrArgs g)
+{
+    constexpr int TR = RC_TR, CW = RC_CW, T = RC_T, XR = TR + T - 1, XC = CW + T - 1, NC = D * T, NV = 4 * D * T + 4 * D;
+    extern __shared__ float rc_sh[];
+    float* s0t = rc_sh;                                   // [D][TR][CW]
+    float* xt = rc_sh + D * TR * CW;                      // [D][XR][XC]
+    const int i0 = blockIdx.x * TR, j0 = blockIdx.y * CW;
+    const long bb = blockIdx.z, plane = (long)g.Nx * g.Ny;
+    // stage: s0 = out - in (zero outside the image), in shifted: tile (r, c) <-> image (i0 - 2 ik0 - 4 + r, j0 - 2 il0 - 4 + c), zero outside [lo, N).
+    // Every global load of the workgroup is issued before the first LDS store (clamped addresses, masks applied on the way to LDS): a
+    // rolled load -> store loop is one memory round trip per iteration.
+    {
+        constexpr int NQ = D * TR * (CW / 4) / 256;                      // float4s of the error tile per thread (6 for D = 3)
+        static_assert(D * TR * (CW / 4) % 256 == 0, "error tile: whole float4s per thread");
+        constexpr int NX = (D * XR * XC + 255) / 256;                    // elements of the input tile per thread (37 for D = 3)
+        float4 vo[NQ], vi[NQ];
+        float vx[NX];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int t = u * 256 + threadIdx.x;
+            const int d = t / (TR * (CW / 4)), rem = t - d * TR * (CW / 4), r = rem / (CW / 4), c = (rem - r * (CW / 4)) * 4;
+            const int i = min(i0 + r, g.Nx - 1), j = min(j0 + c, g.Ny - 4);
+            const long idx = (bb * D + d) * plane + (long)i * g.Ny + j;
+            vo[u] = *reinterpret_cast<const float4*>(g.out + idx);
+            vi[u] = *reinterpret_cast<const float4*>(g.in + idx);
+        }
+        const int xi0 = i0 - 2 * g.ik0 - (T - 1), xj0 = j0 - 2 * g.il0 - (T - 1);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int t = min(u * 256 + (int)threadIdx.x, D * XR * XC - 1);
+            const int d = t / (XR * XC), rem = t - d * XR * XC, r = rem / XC, c = rem - r * XC;
+            const int i = min(max(xi0 + r, 0), g.Nx - 1), j = min(max(xj0 + c, 0), g.Ny - 1);
+            vx[u] = g.in[(bb * D + d) * plane + (long)i * g.Ny + j];
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int t = u * 256 + threadIdx.x;
+            const int d = t / (TR * (CW / 4)), rem = t - d * TR * (CW / 4), r = rem / (CW / 4), c = (rem - r * (CW / 4)) * 4;
+            const bool ok = i0 + r < g.Nx && j0 + c < g.Ny;               // (Ny is a multiple of 4: a quad is inside or outside as a whole)
+            const float4 v = ok ? make_float4(vo[u].x - vi[u].x, vo[u].y - vi[u].y, vo[u].z - vi[u].z, vo[u].w - vi[u].w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(s0t + (d * TR + r) * CW + c) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int t = u * 256 + threadIdx.x;
+            if (t < D * XR * XC) {
+                const int d = t / (XR * XC), rem = t - d * XR * XC, r = rem / XC, c = rem - r * XC;
+                const int i = xi0 + r, j = xj0 + c;
+                xt[t] = (i >= g.lo && i < g.Nx && j >= g.lo && j < g.Ny) ? vx[u] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int seg = threadIdx.x / NC, combo = threadIdx.x - seg * NC;
+    const int d = combo / T, a = combo - d * T;
+    const int r = seg >> 1, jb = (seg & 1) * (CW / 2);
+    float acc[4][D][T];                                   // column sets: all, column 0, column 1, column Ny-1
+    float ss[4][D];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int d1 = 0; d1 < D; ++d1) {
+            ss[cs][d1] = 0.f;
+#pragma unroll
+            for (int b = 0; b < T; ++b) acc[cs][d1][b] = 0.f;
+        }
+    const bool active = seg < RC_NSEG && i0 + r < g.Nx;
+    if (active) {
+        // x at image (i - u_i, j - u_j), u = 2 ik0 + (a, b): tile row r + (T-1-a), tile column jj + (T-1-b)
+        const float* xrow = xt + (d * XR + r + (T - 1 - a)) * XC;
+        const float* srow = s0t + r * CW;
+        float w[T];
+#pragma unroll
+        for (int b = 1; b < T; ++b) w[b] = xrow[jb + (T - 1 - b)];
+        const int jend = min(jb + CW / 2, g.Ny - j0);
+        // (the next pixel's LDS reads are issued before this pixel's FMAs: two workgroups per CU leave little else to hide their latency)
+        float wn = xrow[jb + T - 1], svn[D];
+#pragma unroll
+        for (int d1 = 0; d1 < D; ++d1) svn[d1] = srow[d1 * TR * CW + jb];
+        for (int jj = jb; jj < jend; ++jj) {
+            w[0] = wn;
+            float sv[D];
+#pragma unroll
+            for (int d1 = 0; d1 < D; ++d1) sv[d1] = svn[d1];
+            const int jn = min(jj + 1, jb + CW / 2 - 1);
+            wn = xrow[jn + T - 1];
+#pragma unroll
+            for (int d1 = 0; d1 < D; ++d1) svn[d1] = srow[d1 * TR * CW + jn];
+#pragma unroll
+            for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) acc[0][d1][b] = fmaf(sv[d1], w[b], acc[0][d1][b]);
+                ss[0][d1] += sv[d1];
+            }
+            const int gj = j0 + jj;
+            if (gj <= 1 || gj == g.Ny - 1) {
+                const int cs = gj == 0 ? 1 : (gj == 1 ? 2 : 3);
+#pragma unroll
+                for (int c2 = 1; c2 < 4; ++c2)
+                    if (c2 == cs) {
+#pragma unroll
+                        for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+                            for (int b = 0; b < T; ++b) acc[c2][d1][b] = fmaf(sv[d1], w[b], acc[c2][d1][b]);
+                            ss[c2][d1] += sv[d1];
+                        }
+                    }
+            }
+#pragma unroll
+            for (int b = T - 1; b > 0; --b) w[b] = w[b - 1];
+        }
+    }
+    __syncthreads();
+    // per-thread sums -> LDS [seg][combo][NV], then the workgroup's partial per row class, segments added in order
+    float* red = rc_sh;
+    if (seg < RC_NSEG) {
+        float* q = red + (seg * NC + combo) * NV;
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+            for (int d1 = 0; d1 < D; ++d1) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) q[(cs * D + d1) * T + b] = acc[cs][d1][b];
+                q[4 * D * T + cs * D + d1] = ss[cs][d1];
+            }
+    }
+    __syncthreads();
+    constexpr int NR = D * D * T * T, PW = rc_pw<D>();
+    float* dst = g.part + ((bb * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * (long)PW;
+    for (int e = threadIdx.x; e < PW; e += 256) {
+        int rc, cs, d1, cmb, off;
+        if (e < 16 * NR) {
+            rc = e / (4 * NR); int rem = e - rc * 4 * NR;
+            cs = rem / NR; rem -= cs * NR;
+            d1 = rem / (D * T * T); rem -= d1 * D * T * T;
+            const int dd = rem / (T * T); rem -= dd * T * T;
+            const int aa = rem / T, b = rem - aa * T;
+            cmb = dd * T + aa; off = (cs * D + d1) * T + b;
+        } else {
+            const int e2 = e - 16 * NR;
+            rc = e2 / (4 * D); const int rem = e2 - rc * 4 * D;
+            cs = rem / D; d1 = rem - cs * D;
+            cmb = 0; off = 4 * D * T + cs * D + d1;                       // (every combo of a segment holds the same s0 sums)
+        }
+        float v = 0.f;
+        for (int sg = 0; sg < RC_NSEG; ++sg) {
+            const int i = i0 + (sg >> 1);
+            const int cls = i == 0 ? 0 : (i == 1 ? 1 : (i == g.Nx - 1 ? 2 : 3));
+            if (cls == rc && i < g.Nx) v += red[(sg * NC + cmb) * NV + off];
+        }
+        dst[e] = v;
+    }
+}
+
+// the workgroups' partials summed in RC_NCH chunks (thread = element, consecutive threads read consecutive floats of one partial; the
+// partials of a chunk are added in order): tmp[chunk][pw].  dc_from_regions_kernel adds the chunks.
+constexpr int RC_NCH = 16;
+__global__ __launch_bounds__(256) void rcorr_sum_kernel(const float* __restrict__ part, float* __restrict__ tmp, int nparts, int pw)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= pw) return;
+    const int per = (nparts + RC_NCH - 1) / RC_NCH;
+    const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+    float s = 0.f;
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long)(p + u) * pw + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < p1; ++p) s += part[(long)p * pw + e];
+    tmp[(long)blockIdx.y * pw + e] = s;
+}
+
+// dC, dB from the region sums:  R_t1 = sum over the row classes whose row r has lo <= r - ik1 < Nx of (all columns - the columns c in {0, 1, Ny-1}
+// with c - il1 outside [lo, Ny));  gc[m][d][k][l] = sum_{d1,k1,l1} f[d1][m][k1][l1] R_(k1,l1)[d1][d][k1+k][l1+l],  gb[m] likewise from the s0 sums
+template <int D>
+__global__ __launch_bounds__(256) void dc_from_regions_kernel(const float* __restrict__ f, const float* __restrict__ tmp, float* __restrict__ gc,
+                                                              float* __restrict__ gb, int dM, int Nx, int Ny, int ik0, int il0, int lo, float scale)
+{
+    constexpr int NK = 3, KK = 9, T = RC_T, NR = D * D * T * T, PW = rc_pw<D>();
+    __shared__ float reg[PW];
+    for (int e0 = 0; e0 < PW; e0 += 256 * 2) {
+        float v[2][RC_NCH];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < RC_NCH; ++c) v[u][c] = tmp[(long)c * PW + min(e0 + u * 256 + (int)threadIdx.x, PW - 1)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < RC_NCH; ++c) sacc += v[u][c];
+            const int e = e0 + u * 256 + threadIdx.x;
+            if (e < PW) reg[e] = sacc * scale;
+        }
+    }
+    __syncthreads();
+    // R of every tap t1 = (k1, l1) from the regions its mask admits: Rt[t1][d1][d][u] and the masked s0 sums St[t1][d1]
+    constexpr int NT = KK * (NR + D);
+    __shared__ float Rt[NT];
+    const int rowpos[3] = {0, 1, Nx - 1}, colpos[3] = {0, 1, Ny - 1};
+    for (int e = threadIdx.x; e < NT; e += 256) {
+        const int t1 = e / (NR + D), r2 = e - t1 * (NR + D);
+        const int k1 = t1 / NK, l1 = t1 - k1 * NK, ik1 = ik0 + k1, il1 = il0 + l1;
+        float R = 0.f;
+        for (int rc = 0; rc < 4; ++rc) {
+            if (rc < 3 && !(rowpos[rc] - ik1 >= lo && rowpos[rc] - ik1 < Nx)) continue;      // (the rows of class 3 pass for every tap)
+            auto at = [&](int cs) { return r2 < NR ? reg[(rc * 4 + cs) * NR + r2] : reg[16 * NR + (rc * 4 + cs) * D + (r2 - NR)]; };
+            float v = at(0);
+            for (int c = 0; c < 3; ++c) if (!(colpos[c] - il1 >= lo && colpos[c] - il1 < Ny)) v -= at(1 + c);
+            R += v;
+        }
+        Rt[e] = R;
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nw = dM * D * KK;
+    if (idx >= nw + dM) return;
+    const bool isb = idx >= nw;
+    const int m = isb ? idx - nw : idx / (D * KK);
+    const int rr = isb ? 0 : idx - m * D * KK, d = rr / KK, kl = rr - d * KK, k = kl / NK, l = kl - k * NK;
+    float s = 0.f;
+#pragma unroll
+    for (int d1 = 0; d1 < D; ++d1)
+#pragma unroll
+        for (int k1 = 0; k1 < NK; ++k1)
+#pragma unroll
+            for (int l1 = 0; l1 < NK; ++l1) {
+                const float* Rb = Rt + (k1 * NK + l1) * (NR + D);
+                const float R = isb ? Rb[NR + d1] : Rb[(d1 * D + d) * T * T + (k1 + k) * T + (l1 + l)];
+                s = fmaf(f[((long)(d1 * dM + m) * NK + k1) * NK + l1], R, s);
+            }
+    if (isb) gb[m] = s; else gc[idx] = s;
+}
+
+// floats of SpatialGradArgs::rq (the region sums)
+size_t spatial_rq_floats(int dD, int Nk, int Nl) { (void)Nk; (void)Nl; return (size_t)RC_NCH * 16 * ((size_t)dD * dD * RC_T * RC_T + dD); }
+
+static bool rcorr_ok(const SpatialGradArgs& a)
+{
+    return a.rq && a.Nk == 3 && a.Nl == 3 && (a.dD == 3 || a.dD == 1) && a.dM >= 8 && a.Nx >= 8 && a.Ny >= 8 && a.Ny % 4 == 0 && a.lo <= 1 && a.ak == 0 && a.al == 0 &&
+           !flag(AEFFT_F_NOMFMA) && !flag(AEFFT_F_NORCORR);
+}
+
+template <int D> static hipError_t run_rcorr(const SpatialGradArgs& a, float scale, hipStream_t st)
+{
+    const int ik0 = -2 * a.ak - 1, il0 = -2 * a.al - 1;
+    const dim3 grid((a.Nx + RC_TR - 1) / RC_TR, (a.Ny + RC_CW - 1) / RC_CW, a.B);
+    const size_t lds = sizeof(float) * std::max<size_t>((size_t)D * RC_TR * RC_CW + (size_t)D * (RC_TR + RC_T - 1) * (RC_CW + RC_T - 1),
+                                                        (size_t)RC_NSEG * D * RC_T * (4 * D * RC_T + 4 * D));
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rcorr_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    RCorrArgs g{a.out, a.in, a.part, a.B, a.Nx, a.Ny, ik0, il0, a.lo};
+    rcorr_kernel<D><<<grid, 256, lds, st>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nparts = (int)(grid.x * grid.y * grid.z), pw = rc_pw<D>();
+    rcorr_sum_kernel<<<dim3((pw + 255) / 256, RC_NCH), 256, 0, st>>>(a.part, a.rq, nparts, pw);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int total = a.dM * D * 9 + a.dM;
+    dc_from_regions_kernel<D><<<dim3((total + 255) / 256), 256, 0, st>>>(a.f, a.rq, a.gc, a.gb, a.dM, a.Nx, a.Ny, ik0, il0, a.lo, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
 {
+    if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL) && rcorr_ok(a)) {
+        // dC, dB through the error-input correlation (no back-convolved error); dF, dP as the hidden-layer correlation on the matrix cores
+        const float scale = 1.0f / a.Norm / (float)a.B;
+        hipError_t e = a.dD == 3 ? run_rcorr<3>(a, scale, st) : run_rcorr<1>(a, scale, st);
+        if (e != hipSuccess) return e;
+        MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part, 0, 1, 0, 0, 0};
+        return run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st);
+    }
     if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL)) {
         // g = back-convolution of s0 = out - in through f (zero for i' < lo or j' < lo)
         DConvArgs g{};
@@ -1094,8 +1420,8 @@ hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
             //   dC[m][d][k][l] = sum g[m][i][j] in[d][i-ik][j-il]                  rows g, columns in shifted by -tap, + ones column (dB)
             //   dF[d][m][k][l] = sum s0[d][i][j] hin[m][i-ik][j-il]                 re-indexed by i' = i - ik: rows hin (masked below lo),
             //                  = sum hin[m][i'][j'] s0[d][i'+ik][j'+il]             columns s0 shifted by +tap, + ones row (dP at the zero tap)
-            MCorrArgs mc{a.ws, a.dM, 0, a.in, nullptr, a.dD, a.lo, -1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 0, 1, 0, 0, a.part};
-            MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part};
+            MCorrArgs mc{a.ws, a.dM, 0, a.in, nullptr, a.dD, a.lo, -1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 0, 1, 0, 0, a.part, 0, 1, 0, 0, 0};
+            MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part, 0, 1, 0, 0, 0};
             if (a.Nk == 3) { e = run_mcorr<3>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
             else if (a.Nk == 5) { e = run_mcorr<5>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<5>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
             else { e = run_mcorr<7>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<7>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }

@@ -778,7 +778,7 @@ hipError_t launch_diff_mse(const float2* T, const float2* O, float2* E, float* m
 // DC-bin bias of the collapsed pair operator O = G X + beta (conv_k o conv_k, fft.cu:183-184 twice):
 //   beta[d'] = p[d'] + sum_m F[d'][m](0,0) b[m] / dD          (times Nx*Ny where it is applied)
 __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, float* __restrict__ copy2, int L,
-                                                               const BetaArgs ba)
+                                                               const BetaArgs ba, float prev_scale)
 {
     __shared__ float ws[MSE_SLOTS / 64];
     __shared__ float bacc[256];
@@ -806,17 +806,19 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
             for (int w = 0; w < MSE_SLOTS / 64; ++w) t += ws[w];
             out[l] = t;
             if (copy) copy[l] = t;
-            if (copy2) copy2[l] = t;
+            // the packed buffer's tail: what the caller's all-reduce left there (the sum over ranks of the PREVIOUS step's MSEs) is kept,
+            // scaled to the global mean, in the L floats behind the tail before this step's local value takes its place
+            if (copy2) { copy2[L + l] = copy2[l] * prev_scale; copy2[l] = t; }
         }
         __syncthreads();
     }
 }
 
-hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba, float* copy2)
+hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba, float* copy2, float prev_scale)
 {
     BetaArgs a{};
     if (ba && ba->dD <= 256) a = *ba;
-    mse_finish_kernel<<<a.beta ? 2 : 1, MSE_SLOTS, 0, st>>>(slots, out, copy, copy2, L, a);
+    mse_finish_kernel<<<a.beta ? 2 : 1, MSE_SLOTS, 0, st>>>(slots, out, copy, copy2, L, a, prev_scale);
     return hipGetLastError();
 }
 

@@ -90,14 +90,16 @@ class DataParallelStep:
                 if ev: ev[1].record(st)
                 scale = allreduce_sum_(self.gbuf, self.group)
                 if ev: ev[2].record(st)
-                # the tail now holds the sum over ranks of the previous step's post-update MSEs: keep the global mean before
-                # aefft_net_step_apply overwrites the tail with this step's local values
-                self._mse_prev = self.gbuf[self.tail] * scale
+                # the tail now holds the sum over ranks of the previous step's post-update MSEs: aefft_net_step_apply itself saves the
+                # global mean behind the buffer before its own values take the tail (nothing is enqueued here: a kernel between the
+                # collective and the update half would sit on the step's critical path)
+                self._mse_prev = self.net.mse_prev_global()
         else:
             # no process group: nothing is enqueued between the two halves (a kernel there -- even the 4-float copy of the tail --
             # is a launch on the step's critical path); the step's own MSEs are the global ones (`mse` of aefft_net_step_apply)
             scale = 1.0
             if ev: ev[1].record(st); ev[2].record(st)
+            self._mse_prev = self.net.mse_prev_global()
         self._scale = scale
         self.net.step_apply(del0, maxdiff, sym, scale, mse)
         if ev:
@@ -105,8 +107,8 @@ class DataParallelStep:
             self.timers.append(ev)
 
     def mse_tail(self):
-        """global-batch post-update MSE per pair of the step BEFORE the last one (it travelled in the last gradient all-reduce); None before the
-        second step and without a process group (the `mse` output of the step is then already global)"""
+        """global-batch post-update MSE per pair of the step BEFORE the last one (it travelled in the last gradient all-reduce and was saved
+        behind the packed buffer by the last aefft_net_step_apply): a stream-ordered view, valid until the next step; zeros after the first step"""
         return self._mse_prev
 
     def flush_mse(self):

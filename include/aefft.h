@@ -74,7 +74,8 @@ enum {
     AEFFT_F_NOOPFORM = 1 << 16,   /* training step per frame (batch contractions) instead of the operator form */
     AEFFT_F_NOCHAIN = 1 << 17,    /* operator form: the network on the basis frames layer by layer instead of one fused launch */
     AEFFT_F_NOFUSEUPD = 1 << 18,  /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
-    AEFFT_F_NOAHEAD = 1 << 19     /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
+    AEFFT_F_NOAHEAD = 1 << 19,    /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
+    AEFFT_F_NORCORR = 1 << 20     /* spatial mode: dC through the back-convolved error (a dM-plane tensor) instead of the error-input correlation R */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);
@@ -249,7 +250,8 @@ int aefft_net_set_input_ready(aefft_net* net, int enable);
  * (zero before the first).  A data-parallel caller all-reduces (SUM) the whole buffer: the gradients are then applied with grad_scale =
  * 1/world, and the tail times 1/world is the global-batch MSE of the previous step (the MSE rides in the gradients' message;
  * the post-update MSE of a step needs that step's reduced gradients, so it travels one step behind).  aefft_net_step_apply reads the
- * gradient part only and overwrites the tail. */
+ * gradient part only and overwrites the tail; what it finds there it first saves, times its grad_scale, in the L floats BEHIND the
+ * buffer (buf_d[nfloats .. nfloats + L), not part of the message): after step_apply of step t+1 they hold the global-batch MSE of step t. */
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 /* Which form the NEXT aefft_net_step_grad / _apply of this net runs in (decided by the net's shapes and the development switches; the
  * arithmetic is the reference's in every form, re-associated -- DESIGN.md section 4):

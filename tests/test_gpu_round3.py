@@ -292,3 +292,29 @@ def test_c_level_step_with_rccl_on_the_library_stream():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RANK="0", WORLD_SIZE="1")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "rccl_step ok" in out.stdout, (out.stdout, out.stderr[-2000:])
+
+
+def test_step_apply_saves_the_reduced_mse_tail_behind_the_packed_buffer(ctx):
+    """SURVEY 8e / include/aefft.h: the packed buffer's tail carries the previous step's post-update MSEs through the caller's all-reduce;
+    aefft_net_step_apply keeps what it finds there, times grad_scale, in the L floats behind the buffer before its own values take the
+    tail -- so that no copy kernel has to be enqueued between the collective and the update half."""
+    rng = np.random.default_rng(77)
+    D, N, maps, Nk, s, B = 3, 32, [4, 6], 5, 2, 2
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    dD = D
+    for l, dM in enumerate(maps):
+        net.set_pair(l, rng.uniform(-1, 1, (dM, dD, Nk, Nk)), rng.uniform(-1, 1, dM), rng.uniform(-1, 1, (dD, dM, Nk, Nk)), rng.uniform(-1, 1, dD)); dD = dM
+    x = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    mse = ctx.empty(len(maps))
+    L = len(maps)
+    net.step_grad(x, None); net.step_apply(0.02, 0, 0, 1.0, mse)
+    m1 = host(mse).copy()
+    assert np.array_equal(host(net.mse_prev_global()), np.zeros(L, np.float32))          # nothing before the first step
+    assert np.array_equal(host(net.grad_buffer())[-L:], m1)
+    net.step_grad(x, None)
+    net.grad_buffer()[-L:] *= 2.0                                                          # a two-rank all-reduce (SUM) of equal tails
+    net.step_apply(0.02, 0, 0, 0.5, mse)
+    m2 = host(mse).copy()
+    assert np.allclose(host(net.mse_prev_global()), m1, rtol=1e-6)                          # global mean of step 1, saved by step 2's update half
+    assert np.array_equal(host(net.grad_buffer())[-L:], m2)
+    net.close()

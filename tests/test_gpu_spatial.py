@@ -212,3 +212,32 @@ def test_b11_compat_switch_reproduces_the_cuda_source(ctx, dD, dM, N, Nk):
         for got, ref, k in zip(res[sem], (gc, gb, gf, gp), ("gc", "gb", "gf", "gp")):
             assert np.abs(got - ref).max() < 2e-5 * max(np.abs(ref).max(), 1e-30), (sem, k)
     assert not np.allclose(res["gpu"][2], res["cuda_compat"][2])
+
+
+@pytest.mark.parametrize("dD,dM,N,B,tied,sem", [(3, 8, 24, 2, False, "gpu"), (1, 9, 40, 1, False, "gpu"), (3, 50, 16, 3, True, "gpu"),
+                                                (3, 8, 264, 1, False, "gpu"), (3, 12, 36, 2, False, "cpu"), (1, 8, 20, 1, True, "cpu")])
+def test_backprop_kernel_gradient_through_the_error_input_correlation(ctx, flags, dD, dM, N, B, tied, sem):
+    """a14/a15, 3x3 supports with <= 3 input channels: dC and dB through the region sums of the error-input correlation (rcorr_kernel:
+    no back-convolved error tensor) == the route through the back-convolved error (switch NORCORR) == the oracle -- border rows and
+    columns included (rows 0, 1, N-1 are their own regions), several row bands, two column blocks (N = 264), both boundary semantics,
+    and with a hidden layer that is NOT conv(in): the hidden layer enters dF only, as the caller passed it."""
+    rng = np.random.default_rng(N + dM + dD)
+    x, c, b, f, p = _case(rng, dD, dM, N, 3, B)
+    hin = rng.uniform(-50, 50, (B, dM, N, N)).astype(np.float32)
+    out = (x + rng.uniform(-20, 20, x.shape)).astype(np.float32)
+    mom = [np.zeros_like(a) for a in (c, b, f, p)]
+    res = []
+    for fl in ((), ("NORCORR",)):
+        flags(*fl)
+        t = [ctx.dev(a) for a in (x, out, hin, c, b, f, p)]
+        tm = [ctx.dev(a) for a in mom]
+        tg = [ctx.dev(np.zeros_like(a)) for a in (c, b, f, p)]
+        ctx.backprop_spatial(*t, tm, tg, 0.2, 0.9, tied=tied, semantics=sem)
+        res.append([host(g).copy() for g in tg])
+    for k, (g0, g1) in zip(("ddc", "ddb", "ddf", "ddp"), zip(*res)):
+        assert np.abs(g0 - g1).max() <= 3e-5 * max(np.abs(g1).max(), 1e-30), k
+    if sem == "gpu":
+        ref = S.backprop_gpu(list(x), list(out), list(hin), c, b, f, p, mom[0], mom[1], mom[2], mom[3], 0.2, 0.9, tied=tied, B_mean=True)
+        for k, g, r in zip(("ddc", "ddb", "ddf", "ddp"), res[0], ref[8:]):
+            if r is not None:
+                assert np.abs(g - r).max() < 3e-5 * max(np.abs(r).max(), 1e-30), k

@@ -5,6 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 aefft = importlib.import_module("autoencoder-fft_amd")
 ctx = aefft.Context(0)
+if os.environ.get("FLAGS"): ctx.set_flags(*os.environ["FLAGS"].split(","))
 B, dD, dM, N, Nk = int(os.environ.get("B", "32")), 3, int(os.environ.get("M", "50")), int(os.environ.get("N", "256")), int(os.environ.get("NK", "3"))
 rng = np.random.default_rng(0)
 x = ctx.dev(np.floor(rng.uniform(0, 256, (B, dD, N, N))))
@@ -20,5 +21,12 @@ for it in range(3):
     ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
     pr = ctx.prof_read()
 print({k: round(v["ms"] * 1e3, 1) for k, v in pr.items() if v["launches"]})
+ctx.prof_enable(False)
+def step():
+    h = ctx.conv_spatial(x, c, b); o = ctx.conv_spatial(h, f, p); ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
+for _ in range(3): step()
+ctx.sync(); t0 = time.perf_counter()
+for _ in range(20): step()
+ctx.sync(); print(f"step {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms (flags {os.environ.get('FLAGS', '')})")
 flops_conv = 2.0 * B * dM * dD * Nk * Nk * N * N
 print(f"conv flops {flops_conv/1e9:.2f} GF each")
