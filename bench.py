@@ -199,11 +199,22 @@ def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2
     name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_s = dom["ms"] / dom["launches"] * 1e-3
     ach = dom["bytes"] / dom["launches"] / avg_s / 1e9 if avg_s else 0.0
+    roof = {"bound": "hbm", "kernel": KERNEL_NAMES.get(name, name), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "share_of_kernel_time": dom["ms"] / sum(v["ms"] for v in prof.values()), "traffic": None}
+    if name == "gradient_diff":
+        # the multiobjective term is arithmetic, not traffic: per kernel pair Nk*Nl subtractions, 2 Nk*Nl FMAs and a reciprocal
+        # (fft_backproplib.cu:709-753 re-associated, update_kernels.hip) against the fp32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+        dD, flops = 3, 0.0
+        for dM in maps:
+            flops += 2.0 * (dM * dD) ** 2 * (5.0 * Nk * Nk + 1.0); dD = dM
+        t_s = dom["ms"] / 2 * 1e-3
+        roof = {"bound": "valu", "kernel": KERNEL_NAMES.get(name, name), "achieved": flops / t_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": flops / t_s / 1e12 / 157.3, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_flops_per_step": flops,
+                "share_of_kernel_time": dom["ms"] / sum(v["ms"] for v in prof.values()), "traffic": None}
     return {"workload": label, "step_form": form, "frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": steps, "mse_first": mse_first, "mse_last": mse_last,
             "mse_finite": bool(np.isfinite(mse_last).all()), "step_algo_GB": step_bytes / 1e9, "step_frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(name, name), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_bytes_per_launch": dom["bytes"] / dom["launches"],
-                         "share_of_kernel_time": dom["ms"] / sum(v["ms"] for v in prof.values()), "traffic": None}}
+            "roofline": roof}
 
 
 def variant_spatial(aefft, torch, np, ctx, steps=5):
@@ -232,10 +243,16 @@ def variant_spatial(aefft, torch, np, ctx, steps=5):
     ctx.sync(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     conv_flops = 2.0 * B * dM * dD * Nk * Nk * N * N
-    flops = 5 * conv_flops                     # 2 convs + back-conv + 2 gradient correlations
+    # work of the groups AS LAUNCHED: conv 3->50, conv 50->3, the dF correlation (hidden layer x error: one conv-sized GEMM) and the
+    # error-input correlation behind dC (dD x dD x 25 sums per pixel) -- the back-convolved error and its correlation of rounds 1-2 no longer exist
+    flops = 3 * conv_flops + 2.0 * B * dD * dD * 25 * N * N
+    act, hid = 4.0 * B * dD * N * N, 4.0 * B * dM * N * N        # bytes of a 3-plane and of the 50-plane tensor
+    algo_bytes = (act + hid) + (hid + act) + (hid + 2 * act) + 2 * act      # conv, conv, dF correlation (hin, out, in), error-input correlation (out, in)
     return {"workload": f"spatial mode: Conv_gpu+Conv_gpu+backprop_gpu, {B} frames {N}x{N}x{dD}, {dM} maps, {Nk}x{Nk}", "frames_per_s": B / dt,
-            "ms_per_step": dt * 1e3, "steps": steps, "algo_TFLOP_per_step": flops / 1e12,
-            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3}}
+            "ms_per_step": dt * 1e3, "steps": steps, "algo_TFLOP_per_step": flops / 1e12, "step_algo_GB": algo_bytes / 1e9,
+            "roofline": {"bound": "hbm", "achieved": algo_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                         "note": "whole step; the binding bound: the 50-map hidden layer (419 MB) is written once and read twice"},
+            "mfma_roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3}}
 
 
 def spawn_ranks(a):
@@ -381,10 +398,6 @@ def main():
         roof["step_algo_GB"] = step_bytes / 1e9
         roof["step_frac_of_hbm_peak"] = step_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(N, s if s > 1 else 2)
-
     variants = None
     if rank == 0 and world == 1 and not a.no_variants and a.variant == "p2" and a.size == 512:
         net.close()
@@ -401,6 +414,11 @@ def main():
             "cfg5": fft_variant(aefft, torch, np, ctx, "cfg5 per-GPU shape: 1024x1024x3, 5 pairs 3->8->...->128, 5x5, pool 2/layer, tied weights + "
                                 "multiobjective (sym=1, maxdiff=1), 32 frames (BASELINE configs[4])", 1024, M5, 2, 32, steps=10, warmup=2, sym=1, maxdiff=1),
             "spatial": variant_spatial(aefft, torch, np, ctx)}
+
+    # (the CPU baseline last: its 16 worker processes leave the host's CPU share throttled for a moment, which the launch-bound variants would see)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(N, s if s > 1 else 2)
 
     if rank == 0:
         out = {
