@@ -84,8 +84,12 @@ int main()
         CK(aefft_net_step_apply(net, 0.2f, 0, 0, 1.0f / (float)world, mse));
         if (it == 1) HK(hipMemcpyAsync(m_prev.data(), mse, L * 4, hipMemcpyDeviceToHost, st));
     }
+    std::vector<float> saved(L);
+    HK(hipMemcpyAsync(saved.data(), gbuf + gn, L * 4, hipMemcpyDeviceToHost, st));      // behind the buffer: the reduced tail times grad_scale, saved by the last step_apply
     CK(aefft_sync(ctx));
     int bad = 0;
+    for (int l = 0; l < L; ++l)
+        if (std::fabs(saved[l] - tail_after[l] / (float)world) > 1e-6f * std::fabs(saved[l])) { fprintf(stderr, "saved global MSE != reduced tail / world (pair %d: %g vs %g)\n", l, saved[l], tail_after[l] / (float)world); ++bad; }
     for (int l = 0; l < L; ++l) {
         if (std::fabs(tail_before[l] - m_prev[l]) > 1e-6f * std::fabs(m_prev[l])) { fprintf(stderr, "tail != previous step's MSE (pair %d: %g vs %g)\n", l, tail_before[l], m_prev[l]); ++bad; }
         if (world == 1 && tail_after[l] != tail_before[l]) { fprintf(stderr, "all-reduce at world 1 changed the tail\n"); ++bad; }
