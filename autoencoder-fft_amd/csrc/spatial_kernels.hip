@@ -22,6 +22,20 @@
 
 namespace aefft {
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, so tiles that are neighbours in the image --
+// and share the cache lines of their halos (a 64-pixel tile row with a one-pixel halo touches 4 lines of 128 B for 2 lines of payload) -- land
+// in 8 different L2s and each fetches those lines from the fabric.  Remapped, every XCD walks a contiguous range of the (tile, frame)
+// sequence: neighbours meet in the same L2 at nearly the same time.  (Launches with one map tile, gridDim.y == 1; otherwise identity.)
+__device__ __forceinline__ void xcd_tile_order(int& bx, long& bz)
+{
+    const long total = (long)gridDim.x * gridDim.z;
+    if (gridDim.y != 1 || (total & 7) != 0) return;
+    const long lin = blockIdx.x + (long)gridDim.x * blockIdx.z;
+    const long logical = (lin & 7) * (total >> 3) + (lin >> 3);
+    bx = (int)(logical % gridDim.x); bz = logical / gridDim.x;
+}
+
+
 __global__ __launch_bounds__(256) void conv_spatial_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            const float* __restrict__ c, const float* __restrict__ b,
                                                            int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl, int ak, int al,
@@ -155,20 +169,24 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DConvArgs a)
 // row from an LDS slab (broadcast reads), for 4*NK*TM FMAs -- (2 + NK*TM/4) LDS instructions per 4*NK*TM FMAs instead of
 // NK*(1 LDS + TM scalar).  Workgroup = 16 rows x 64 columns of one frame.  Same staging, tests and summation order (d, k, l).
 // ------------------------------------------------------------------------------------------
+// output rows per thread: 2 share their input rows in registers (21 instead of 36 LDS instructions per 72 FMAs) but double the tile, the
+// staging registers (209 VGPRs) and halve the workgroups: 171 us against 146 at 32 x 256^2 x (50 -> 3) -- one row it is
+constexpr int DCONV4_RW = 1;
 template <int TM, int NK, bool SUB>
 __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
 {
-    constexpr int PX = 4, TC = 16 * PX, TWY = 16 + NK - 1, TWX = ((TC + NK - 1) + 3) & ~3, DC = 4, TSZ = TWY * TWX;
+    constexpr int PX = 4, RW = DCONV4_RW, TR = 16 * RW, TC = 16 * PX, TWY = TR + NK - 1, TWX = ((TC + NK - 1) + 3) & ~3, DC = 4, TSZ = TWY * TWX;
     constexpr int NLD = (DC * TSZ + 255) / 256;           // staged elements per thread and stage
     constexpr int WS = (NK * TM + 3) & ~3;                // weights of one (channel, tap row): [l][t], padded to whole float4
     __shared__ __attribute__((aligned(16))) float tile[DC][TSZ];
     extern __shared__ __attribute__((aligned(16))) float wl[];     // [Din][NK][WS]: ALL weights of this workgroup's maps, staged once
     const int tiles_y = (a.Ny + TC - 1) / TC;
-    const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
+    int bx = blockIdx.x; long bb = blockIdx.z;
+    xcd_tile_order(bx, bb);
+    const int ti = bx / tiles_y, tj = bx - ti * tiles_y;
     const int m0 = blockIdx.y * TM;
-    const long bb = blockIdx.z;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    const int i = ti * 16 + ty, j0 = tj * TC + tx * PX;
+    const int i = ti * TR + ty * RW, j0 = tj * TC + tx * PX;               // the thread's RW rows: i, i + 1
     for (int t = threadIdx.x; t < a.Din * NK * NK * TM; t += 256) {      // (maps past M read the last map: their sums are never stored)
         const int tm = t % TM, l = (t / TM) % NK, k = (t / (TM * NK)) % NK, d = t / (TM * NK * NK);
         const int m = min(m0 + tm, a.M - 1);
@@ -177,11 +195,12 @@ __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
         const int kk = a.sgn < 0 ? NK - 1 - k : k, ll = a.sgn < 0 ? NK - 1 - l : l;
         wl[(d * NK + kk) * WS + ll * TM + tm] = a.w[(long)m * a.w_m + (long)d * a.w_d + k * NK + l];
     }
-    const int r0 = a.sgn < 0 ? ti * 16 - a.ik0 - (NK - 1) : ti * 16 + a.ik0;
+    const int r0 = a.sgn < 0 ? ti * TR - a.ik0 - (NK - 1) : ti * TR + a.ik0;
     const int c0 = a.sgn < 0 ? tj * TC - a.il0 - (NK - 1) : tj * TC + a.il0;
     const long plane = (long)a.Nx * a.Ny;
     // this thread's staged elements: offset inside a stage's DC planes (the same for every stage) and whether the element exists
-    int off[NLD]; unsigned okm = 0, dlq[NLD];
+    static_assert(NLD <= 64, "one mask bit per staged element");
+    int off[NLD]; unsigned long long okm = 0;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
         const int t = u * 256 + threadIdx.x;
@@ -189,14 +208,15 @@ __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
         const int r = r0 + q / TWX, cc = c0 + q % TWX;
         const bool ok = t < DC * TSZ && r >= a.lo_in && r < a.Nx && cc >= a.lo_in && cc < a.Ny;
         off[u] = ok ? dl * (int)plane + r * a.Ny + cc : 0;
-        okm |= (ok ? 1u : 0u) << u;
-        dlq[u] = (unsigned)dl;
+        okm |= (ok ? 1ull : 0ull) << u;
     }
-    float acc[TM][PX];
+    float acc[RW][TM][PX];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-        for (int p = 0; p < PX; ++p) acc[t][p] = 0.f;
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[rw][t][p] = 0.f;
     float v[NLD], v2[SUB ? NLD : 1];
     auto prefetch = [&](int d0) {                          // the next stage's inputs: in flight while this stage computes
         const int nd = min(DC, a.Din - d0);
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
         const float* base2 = SUB ? a.in2 + (bb * a.Din + d0) * plane : nullptr;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            const bool ok = ((okm >> u) & 1u) && (int)dlq[u] < nd;
+            const bool ok = ((okm >> u) & 1ull) && min((u * 256 + (int)threadIdx.x) / TSZ, DC - 1) < nd;
             v[u] = base[ok ? off[u] : 0];
             if (SUB) v2[u] = base2[ok ? off[u] : 0];
             if (!ok) { v[u] = 0.f; if (SUB) v2[u] = 0.f; }
@@ -226,16 +246,19 @@ __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
         __syncthreads();
         if (d0 + DC < a.Din) prefetch(d0 + DC);
         for (int dl = 0; dl < nd; ++dl) {
+            // the RW + NK - 1 input rows of the thread's RW output rows, once per channel (every row serves up to NK tap rows; with one
+            // output row per thread the LDS pipe, not the FMAs, set the pace: 36 LDS instructions per 72 FMAs, now 21)
+            float x[RW + NK - 1][PX + NK - 1];
+#pragma unroll
+            for (int ry = 0; ry < RW + NK - 1; ++ry) {
+                const float* xr = &tile[dl][(ty * RW + ry) * TWX + tx * PX];     // (k, l: tile offsets, see the weight slab)
+                const float4 x4 = *reinterpret_cast<const float4*>(xr);
+                x[ry][0] = x4.x; x[ry][1] = x4.y; x[ry][2] = x4.z; x[ry][3] = x4.w;
+#pragma unroll
+                for (int e = PX; e < PX + NK - 1; ++e) x[ry][e] = xr[e];
+            }
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const float* xr = &tile[dl][(ty + k) * TWX + tx * PX];     // (k, l: tile offsets, see the weight slab)
-                float x[PX + NK - 1];
-                {
-                    const float4 x4 = *reinterpret_cast<const float4*>(xr);
-                    x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
-#pragma unroll
-                    for (int e = PX; e < PX + NK - 1; ++e) x[e] = xr[e];
-                }
                 float w[WS];
 #pragma unroll
                 for (int e = 0; e < WS; e += 4) {
@@ -243,28 +266,34 @@ __global__ __launch_bounds__(256) void dconv4_kernel(const DConvArgs a)
                     w[e] = w4.x; w[e + 1] = w4.y; w[e + 2] = w4.z; w[e + 3] = w4.w;
                 }
 #pragma unroll
-                for (int l = 0; l < NK; ++l)
+                for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-                    for (int t = 0; t < TM; ++t)
+                    for (int l = 0; l < NK; ++l)
 #pragma unroll
-                        for (int p = 0; p < PX; ++p) acc[t][p] = fmaf(w[l * TM + t], x[p + l], acc[t][p]);
+                        for (int t = 0; t < TM; ++t)
+#pragma unroll
+                            for (int p = 0; p < PX; ++p) acc[rw][t][p] = fmaf(w[l * TM + t], x[rw + k][p + l], acc[rw][t][p]);
             }
         }
     }
-    if (i >= a.Nx) return;
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int m = m0 + t;
-        if (m >= a.M) break;
-        const float bs = a.bias ? a.bias[m] : 0.f;
-        float* dst = a.out + (bb * a.M + m) * plane + (long)i * a.Ny + j0;
-        float o[PX];
+    for (int rw = 0; rw < RW; ++rw) {
+        const int ir = i + rw;
+        if (ir >= a.Nx) return;
 #pragma unroll
-        for (int p = 0; p < PX; ++p) o[p] = (i < a.hi_lo || j0 + p < a.hi_lo) ? 0.f : acc[t][p] + bs;
-        if (j0 + PX <= a.Ny && (a.Ny & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        else {
+        for (int t = 0; t < TM; ++t) {
+            const int m = m0 + t;
+            if (m >= a.M) break;
+            const float bs = a.bias ? a.bias[m] : 0.f;
+            float* dst = a.out + (bb * a.M + m) * plane + (long)ir * a.Ny + j0;
+            float o[PX];
 #pragma unroll
-            for (int p = 0; p < PX; ++p) if (j0 + p < a.Ny) dst[p] = o[p];
+            for (int p = 0; p < PX; ++p) o[p] = (ir < a.hi_lo || j0 + p < a.hi_lo) ? 0.f : acc[rw][t][p] + bs;
+            if (j0 + PX <= a.Ny && (a.Ny & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+                for (int p = 0; p < PX; ++p) if (j0 + p < a.Ny) dst[p] = o[p];
+            }
         }
     }
 }
@@ -296,10 +325,11 @@ __global__ __launch_bounds__(256) void mconv_kernel(const DConvArgs a)
     __shared__ float wl[KCP][MT];
     __shared__ float bsl[MT];                               // the block's biases (read 16*MB times per lane by the epilogue)
     const int tiles_y = (a.Ny + TC - 1) / TC;
-    const int ti = blockIdx.x / tiles_y, tj = blockIdx.x - ti * tiles_y;
+    int bx = blockIdx.x; long bb = blockIdx.z;
+    xcd_tile_order(bx, bb);
+    const int ti = bx / tiles_y, tj = bx - ti * tiles_y;
     const int m0 = blockIdx.y * MT;
     if ((int)threadIdx.x < MT) bsl[threadIdx.x] = (a.bias && m0 + (int)threadIdx.x < a.M) ? a.bias[m0 + threadIdx.x] : 0.f;
-    const long bb = blockIdx.z;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, kq = lane >> 5;
     const int r0 = a.sgn < 0 ? ti * TR - a.ik0 - (NK - 1) : ti * TR + a.ik0;
@@ -424,7 +454,7 @@ template <int NK> static hipError_t run_mconv(const DConvArgs& a, int B, hipStre
 template <int NK> static hipError_t run_dconv(const DConvArgs& a, int B, hipStream_t st)
 {
     if (a.M <= 4 && a.Ny >= 64 && (long)a.Nx * a.Ny * 4 < (1L << 31) && (size_t)a.Din * NK * ((NK * 4 + 3) & ~3) * 4 <= 32 * 1024 && !flag(AEFFT_F_NOFAST)) {        // few maps, wide planes: the register-blocked form
-        const int tiles4 = ((a.Nx + 15) / 16) * ((a.Ny + 63) / 64);
+        const int tiles4 = ((a.Nx + 16 * DCONV4_RW - 1) / (16 * DCONV4_RW)) * ((a.Ny + 63) / 64);      // (dconv4_kernel: 16 * DCONV4_RW rows x 64 columns per workgroup)
 #define AEFFT_D4(TMV) { const size_t wb = sizeof(float) * (size_t)a.Din * NK * ((NK * TMV + 3) & ~3);                            \
             if (a.in2) dconv4_kernel<TMV, NK, true><<<dim3(tiles4, 1, B), 256, wb, st>>>(a);                                      \
             else dconv4_kernel<TMV, NK, false><<<dim3(tiles4, 1, B), 256, wb, st>>>(a); }
