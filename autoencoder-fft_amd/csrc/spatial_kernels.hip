@@ -644,10 +644,6 @@ struct MCorrArgs {
     int ones_row, ones_col;                 // append a row / a column of ones
     int row0, col0;                         // first GEMM row / column of this launch's tile (multiples of 64 / 32*NCB)
     float* part;                            // [B * bands][64][32*NCB]
-    // rowKK > 0: the nA rows are MASKED COPIES of nA / rowKK planes of A -- row (plane, k1, l1) is the plane where the pixel shifted back by
-    // the tap, (i - (rik0 + k1), j - (ril0 + l1)), lies in [rlo, N), zero elsewhere (the error through which a back-convolution tap
-    // reaches an existing hidden pixel: R of launch_spatial_grad)
-    int rowKK, rNK, rik0, ril0, rlo;
 };
 
 template <int NK, int NCB, int NRB>
@@ -692,19 +688,6 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
-    // per staged A row of this thread (fixed over the chunks): its plane and the shift of its window
-    const int nplA = a.rowKK > 0 ? a.nA / a.rowKK : a.nA;
-    int rpl[8], rsi[8], rsj[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const int row = (w * 256 + (int)threadIdx.x) / (128 / 4);
-        const int ga = min(a.row0 + row, a.nA - 1);
-        if (a.rowKK > 0) {
-            const int pl = ga / a.rowKK, tap = ga - pl * a.rowKK, k1 = tap / a.rNK;
-            rpl[w] = pl; rsi[w] = a.rik0 + k1; rsj[w] = a.ril0 + (tap - k1 * a.rNK);
-        } else { rpl[w] = ga; rsi[w] = 0; rsj[w] = 0; }
-    }
-    const int lo_rows = a.rowKK > 0 ? a.rlo : a.loA;
     constexpr int BR = 8;                                             // image rows per workgroup (band)
     const int nchunk_c = (a.Ny + CC - 1) / CC, nchunks = (BR / CR) * nchunk_c;
     constexpr int NBL = (TB * TWR * TWC + 255) / 256;
@@ -719,7 +702,8 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
             const int row = t / (CPX / 4), q = (t % (CPX / 4)) * 4;              // GEMM row, pixel quad inside the chunk
             const int i = min(i0 + q / CC, a.Nx - 1), j = min(j0 + q % CC, a.Ny - 4);
             if (NRB == 1 && row >= 32) continue;                                 // (uniform per w: 4 rows per 128 threads... rows 32.. are never multiplied)
-            av[w] = *reinterpret_cast<const float4*>(a.A + (bb * nplA + rpl[w]) * plane + (long)i * a.Ny + j);
+            const int ga = min(a.row0 + row, a.nA - 1);
+            av[w] = *reinterpret_cast<const float4*>(a.A + (bb * a.nA + ga) * plane + (long)i * a.Ny + j);
         }
     };
     auto store_A = [&](int ch, const float4 (&av)[8]) {
@@ -734,11 +718,13 @@ __global__ __launch_bounds__(256) void mcorr_kernel(const MCorrArgs a)
             const bool ones = a.ones_row && ga == a.nA;
             const float vv[4] = {av[w].x, av[w].y, av[w].z, av[w].w};
             float o[4];
+            // (Ny is a multiple of 4 and j of the quad size: a quad is inside the image or outside as a whole; lo <= 1 can only cut its
+            // first element.  One test per quad instead of five per element: the staging instructions, not the MFMAs, set this kernel's pace)
+            const bool in_img = i < a.Nx && j < a.Ny;
+            const bool rowok = ga < a.nA && in_img && i >= a.loA;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool in_img = i < a.Nx && j + e < a.Ny;
-                const int si = i - rsi[w], sj = j + e - rsj[w];
-                float x = (ga < a.nA && in_img && si >= lo_rows && si < a.Nx && sj >= lo_rows && sj < a.Ny) ? vv[e] : 0.f;
+                float x = (rowok && j + e >= a.loA) ? vv[e] : 0.f;
                 if (ones && in_img) x = 1.f;
                 o[e] = x;
             }
@@ -1433,7 +1419,7 @@ hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
         const float scale = 1.0f / a.Norm / (float)a.B;
         hipError_t e = a.dD == 3 ? run_rcorr<3>(a, scale, st) : run_rcorr<1>(a, scale, st);
         if (e != hipSuccess) return e;
-        MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part, 0, 1, 0, 0, 0};
+        MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part};
         return run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st);
     }
     if (a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL)) {
@@ -1450,8 +1436,8 @@ hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
             //   dC[m][d][k][l] = sum g[m][i][j] in[d][i-ik][j-il]                  rows g, columns in shifted by -tap, + ones column (dB)
             //   dF[d][m][k][l] = sum s0[d][i][j] hin[m][i-ik][j-il]                 re-indexed by i' = i - ik: rows hin (masked below lo),
             //                  = sum hin[m][i'][j'] s0[d][i'+ik][j'+il]             columns s0 shifted by +tap, + ones row (dP at the zero tap)
-            MCorrArgs mc{a.ws, a.dM, 0, a.in, nullptr, a.dD, a.lo, -1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 0, 1, 0, 0, a.part, 0, 1, 0, 0, 0};
-            MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part, 0, 1, 0, 0, 0};
+            MCorrArgs mc{a.ws, a.dM, 0, a.in, nullptr, a.dD, a.lo, -1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 0, 1, 0, 0, a.part};
+            MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part};
             if (a.Nk == 3) { e = run_mcorr<3>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
             else if (a.Nk == 5) { e = run_mcorr<5>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<5>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
             else { e = run_mcorr<7>(mc, a.B, a.gc, 0, a.gb, nullptr, scale, st); if (e == hipSuccess) e = run_mcorr<7>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st); }
