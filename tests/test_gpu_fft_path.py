@@ -161,6 +161,29 @@ def test_update(ctx, dD, dM, N, Nk, maxdiff):
     assert relerr(host(got["C"]), refd["C"]) < 5e-6 and relerr(host(got["F"]), refd["F"]) < 5e-6
 
 
+@pytest.mark.parametrize("Nk,Nl,dD,dM", [(3, 5, 2, 3), (5, 5, 12, 30), (3, 3, 16, 20)])
+def test_update_multiobjective_supports_and_chunking(ctx, Nk, Nl, dD, dM):
+    """a10 gradient_diff (fft_backproplib.cu:709-753) through aefft_update: a non-square 3x5 support (the generic kernels with the
+    stored distance matrix), and channel counts whose dM*dD kernels span several row tiles and partner chunks of the register-tiled
+    kernel (360 and 320 kernels: 2 row tiles x 3 chunks), against the oracle's literal loop nest."""
+    rng = np.random.default_rng(Nk * 10 + Nl + dM)
+    N = 16
+    c = rng.uniform(-1, 1, (dM, dD, Nk, Nl)); f = rng.uniform(-1, 1, (dD, dM, Nk, Nl)); b = rng.uniform(-1, 1, dM); p = rng.uniform(-1, 1, dD)
+    xs = np.floor(rng.uniform(0, 256, (dD, N, N))); outs = xs + rng.uniform(-20, 20, xs.shape)
+    X, O = R.fft(xs), R.fft(outs)
+    Cs, Fs = R.kernel_spectrum(c, N, N), R.kernel_spectrum(f, N, N)
+    dc, df, db, dp = R.gradient_k_io(X, X, O, Cs, Fs, b, N, N)
+    mom = [0.01 * rng.normal(size=a.shape) for a in (c, f, b, p)]
+    ref = R.backprop(c, f, b, p, dc, df, db, dp, *mom, N, N, 0.02, 1)
+    t = [ctx.dev(a) for a in (c, f, b, p, Cs, Fs, dc, df, db, dp, *mom)]
+    ctx.update(*t, N, 0.02, 1)
+    start = dict(c=c, f=f, b=b, p=p, Dc=mom[0], Df=mom[1], Db=mom[2], Dp=mom[3])
+    got = dict(zip(["c", "f", "b", "p"], t[:4])); got.update(dict(zip(["Dc", "Df", "Db", "Dp"], t[10:])))
+    for k, r in zip(["c", "f", "b", "p", "Dc", "Df", "Db", "Dp"], ref):
+        dw = max(np.abs(r - start[k]).max(), 1e-12)
+        assert np.abs(host(got[k]) - r).max() < 1e-6 + 1e-3 * dw, k
+
+
 # ------------------------------------------------------------------------------------------
 # resident network vs oracle and golden vectors
 # ------------------------------------------------------------------------------------------
