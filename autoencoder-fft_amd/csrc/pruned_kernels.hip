@@ -675,7 +675,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
 
 // geometry of one problem of the grouped inverse transform
 struct KgGeom { int ppb, S, RB, chunks, pblocks; };
-static constexpr int KG_NT = 512, KG_MAXCHUNKS = 8;
+static constexpr int KG_NT = 512, KG_MAXCHUNKS = 32;     // (8 row chunks unless the problem would then leave most of the chip idle: see kgrad_group_geom)
 static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
 {
     KgGeom o{};
@@ -686,7 +686,10 @@ static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
     while (o.S > 1 && Nx / o.S < 8) --o.S;
     o.RB = (Nx + o.S - 1) / o.S;
     o.chunks = 1;
-    const int cap = std::min(KG_MAXCHUNKS, max_chunks);
+    // few planes on a large grid (the outermost pair of a 1024^2 net: 9 planes of 512 x 257 bins): 8 chunks are 72 workgroups of 64
+    // serial rows each -- the launch's critical path; up to 32 chunks while the problem stays below ~1000 workgroups
+    const long pb = (planes + o.ppb - 1) / o.ppb;
+    const int cap = std::min(pb * 8 >= 1024 ? 8 : KG_MAXCHUNKS, max_chunks);
     if (cap > 1 && o.RB > 16) {
         // one 16-row load batch per slice and chunk while the destination has room for the chunks' partial sums
         int cr = 16 * o.S;

@@ -21,3 +21,10 @@ ctx.sync(); t0 = time.perf_counter()
 for _ in range(steps): net.step_grad(frames, recon); net.step_apply(0.2, maxdiff, sym, 1.0, mse)
 ctx.sync(); dt = (time.perf_counter() - t0) / steps
 print(f"{sys.argv[1]}: {dt*1e3:.3f} ms/step, {B/dt:.0f} frames/s, form {net.step_form()}, mse {mse.cpu().numpy()}")
+if os.environ.get("PROF"):
+    ctx.prof_enable(True)
+    net.step_grad(frames, recon); net.step_apply(0.2, maxdiff, sym, 1.0, mse); ctx.sync(); ctx.prof_reset()
+    for _ in range(3): net.step_grad(frames, recon); net.step_apply(0.2, maxdiff, sym, 1.0, mse)
+    pr = ctx.prof_read(); ctx.prof_enable(False)
+    for k, v in sorted(pr.items(), key=lambda kv: -kv[1]["ms"]):
+        if v["launches"]: print(f"   {k:14s} {v['ms']/3*1e3:8.1f} us/step  {v['launches']/3:4.1f} launches  {v['bytes']/3/1e6:9.1f} MB  {v['bytes']/max(v['ms'],1e-9)/1e6:8.0f} GB/s")
