@@ -1410,7 +1410,10 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // the reconstruction's side stream forks behind the last launch in front of the gradient kernels -- the input transform's column
     // pass, or the chain launch when the operators of the current weights are not at hand (first step, weights set from outside) --
     // through that dispatch's own completion signal
-    const bool want_fork = chain_plan && recon_d && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && !ctx->prof &&
+    // (reconstructions beyond ~256 MB -- 32 frames of 1024^2 -- stay on the context stream: beside their row pass the pruned inverse transform
+    // of S stretches from 42 to 145 us and the side stream costs more than it hides, 1.084 vs 1.057 ms per cfg5 step; at cfg3 it saves 15 of 203 us)
+    const bool overlap_pays = (double)n->B * n->D * n->Nx * n->Ny * 4.0 <= 256e6;
+    const bool want_fork = chain_plan && recon_d && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && overlap_pays && !ctx->prof &&
                            !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
     const bool need_chain = chain_plan && !n->chain_valid;
     bool fork_recorded = false;
@@ -1553,7 +1556,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     }
     if (recon_d) {   // :1373 fft_inv of the up-sampled last output, fused zero-pad
         const bool nooverlap = flag(AEFFT_F_NOOVERLAP);
-        const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && !ctx->prof;
+        const bool async = lazy && ctx->aux[0] != nullptr && !nooverlap && overlap_pays && !ctx->prof;
         n->recon_deferred = nullptr;
         if (async && n->input_ready && !flag(AEFFT_F_NODEFER)) {
             // pipelined loop (aefft_net_set_input_ready): launched by aefft_net_step_grad after the gradient half instead
