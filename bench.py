@@ -217,7 +217,7 @@ def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2
             "roofline": roof}
 
 
-def variant_spatial(aefft, torch, np, ctx, steps=5):
+def variant_spatial(aefft, torch, np, ctx, steps=20):
     """Spatial mode (a13-a15): Conv_gpu -> Conv_gpu -> backprop_gpu on 32 frames 256x256x3, 50 maps, 3x3 (the reference's default
     layer, New_Layer_Param.txt) -- flops roofline: 2*dM*dD*Nk*Nl*Nx*Ny per conv and per gradient correlation, fp32 matrix-core
     peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The convs are bound by their 419 MB output / input streams, not by flops."""
@@ -234,7 +234,7 @@ def variant_spatial(aefft, torch, np, ctx, steps=5):
         o = ctx.conv_spatial(h, f, p)
         ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
 
-    for _ in range(2):
+    for _ in range(5):
         step()
     ctx.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
