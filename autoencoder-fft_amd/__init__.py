@@ -22,7 +22,7 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 # include/aefft.h AEFFT_F_* (development switches; tests/test_abi.py checks this table against the header)
 FLAGS = {n: 1 << i for i, n in enumerate(
     ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
-     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD", "NORCORR"])}
+     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD", "NORCORR", "NOLAZYMSE"])}
 
 
 class AefftError(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "aefft_net_set_input_ready": (_i, [_vp, _i]),
     "aefft_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "aefft_net_step_form": (_i, [_vp]),
+    "aefft_net_last_mse": (_i, [_vp, _vp]),
     "aefft_net_step_apply": (_i, [_vp, _f, _i, _i, _f, _fp]),
     "aefft_net_reset_momentum": (_i, [_vp]),
     "aefft_prof_enable": (_i, [_vp, _i]),
@@ -470,6 +471,13 @@ class Net:
 
     def step_apply(self, del0, maxdiff=0, sym=0, grad_scale=1.0, mse=None):
         self.ctx.check(self.L.aefft_net_step_apply(self.h, del0, maxdiff, sym, grad_scale, _ptr(mse)))
+
+    def last_mse(self, mse=None):
+        """per-pair post-update MSE of the last step_apply (aefft_net_last_mse): sums them now if step_apply(mse=None) left that to the next step"""
+        if mse is None:
+            mse = self.ctx.empty(self.npairs)
+        self.ctx.check(self.L.aefft_net_last_mse(self.h, _ptr(mse)))
+        return mse
 
     def reset_momentum(self):
         self.ctx.check(self.L.aefft_net_reset_momentum(self.h))

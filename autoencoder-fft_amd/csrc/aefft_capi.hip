@@ -109,7 +109,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}, {"NOLAZYMSE", AEFFT_F_NOLAZYMSE}};
 // The switches named by AEFFT_FLAGS stay on for the life of the process: aefft_ctx_set_flags ORs its argument onto them (a test fixture
 // that restores "no flags" does not clear an AEFFT_FLAGS=POISON run).  A name the library does not know is an error, not a silent
 // default run: the first aefft_ctx_create fails with AEFFT_EINVAL and says which.
@@ -948,6 +948,8 @@ struct aefft_net {
     float* mse_pre = nullptr;  // = scratch
     float* mse_post = nullptr; // = scratch + L
     float *gd_out = nullptr, *gd_part = nullptr;   // multiobjective mode: [cd | fd | bd | pd] per pair, and the chunk partial sums (gradient_diff_ws_floats)
+    bool mse_pending = false;   // the slots hold the unsummed post-update MSE of the last aefft_net_step_apply (mse_d == NULL): summed by the next step's wgrad launch or mse_flush
+    float mse_pending_scale = 1.f;
     float* mse_slots = nullptr; // [L][MSE_SLOTS*MSE_SLOT_STRIDE] accumulators of the fused re-forward MSE (zero between uses)
     float* mse_dev = nullptr;  // scratch for bursts
     size_t mse_cap = 0;
@@ -1205,6 +1207,7 @@ extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, con
     return AEFFT_OK;
 }
 
+static int mse_flush(aefft_net* n);
 static int mark_step_point(aefft_net* n);
 // lazy: encoder outputs that are only consumed through pool_fft are computed on the pooled grid alone (the bins the crop
 // discards are never formed; aefft_net_get_layer recomputes such a layer on demand).  The training step uses it.
@@ -1749,6 +1752,7 @@ extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0,
     if (!n || l < 0 || l >= n->L || n_iter < 0) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_train_pair: bad argument");
     aefft_ctx* ctx = n->ctx;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
+    RET_IF(mse_flush(n));
     RET_IF(join_recon(ctx));
     RET_IF(ensure_frames(n));
     Pair& q = n->pr[l];
@@ -1803,6 +1807,19 @@ static int bias_and_kgrad(aefft_net* n, Pair& q)
     if (q.part) return do_c2r_shrink(ctx, q.dc, g, nullptr, q.part, 2 * planes, q.Nx, q.Ny, q.Nk, q.Nl);
     RET_IF(do_c2r_shrink(ctx, q.dc, g, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl));
     return do_c2r_shrink(ctx, q.df, g + nk, n->real, nullptr, planes, q.Nx, q.Ny, q.Nk, q.Nl);
+}
+
+// The slot sums of the last step's post-update MSE when aefft_net_step_apply was told not to deliver them (mse_d == NULL): they ride as a
+// trailing workgroup of the next step's gradient launch (grads_grouped); anything else that needs them first calls this.
+static int mse_flush(aefft_net* n)
+{
+    if (!n->mse_pending) return AEFFT_OK;
+    aefft_ctx* ctx = n->ctx;
+    Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
+    hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, nullptr, n->L, ctx->cur, nullptr, n->grad + n->grad_n, n->mse_pending_scale);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish(deferred)", e);
+    n->mse_pending = false;
+    return AEFFT_OK;
 }
 
 static int grads_grouped(aefft_net* n)
@@ -1920,9 +1937,13 @@ static int grads_grouped(aefft_net* n)
         }
         if (e == hipSuccess && qpath) {
             for (int l = 0; l < n->L; ++l) wg.q[l].nq = pg.chunks[l];
+            if (n->mse_pending) {      // the previous step's MSE sums: one more workgroup of this launch (they reach the packed buffer's tail before the all-reduce)
+                wg.fin_slots = n->mse_slots; wg.fin_out = n->mse_post; wg.fin_tail = n->grad + n->grad_n; wg.fin_L = n->L; wg.fin_scale = n->mse_pending_scale;
+            }
             Bracket br(ctx, KID_WGRAD, wbytes);
             e = launch_wgrad_taps_group(wg, n->pr[0].Nk, ctx->cur);
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "wgrad(group)", e);
+            n->mse_pending = false;
             return AEFFT_OK;
         }
         if (e == hipSuccess) return AEFFT_OK;
@@ -2183,6 +2204,12 @@ static int apply_grouped(aefft_net* n, float del, int maxdiff, int sym, float gs
             if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "opmse", e);
         }
         if (ahead) { n->op_set ^= 1; n->chain_valid = true; }
+        if (!mse_d && !ctx->prof && !flag(AEFFT_F_NOLAZYMSE)) {
+            // nobody asked for the sums now: they are formed by one more workgroup of the next step's gradient launch (before its
+            // all-reduce), by aefft_net_last_mse, or by whatever needs the slots next -- not by a launch of their own
+            n->mse_pending = true; n->mse_pending_scale = gscale;
+            return AEFFT_OK;
+        }
         Bracket br(ctx, KID_DIFFMSE, 4.0 * n->L * MSE_SLOTS);
         hipError_t e = launch_mse_finish(n->mse_slots, n->mse_post, mse_d, n->L, ctx->cur, nullptr, n->grad + n->grad_n, gscale);
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "mse_finish", e);
@@ -2279,7 +2306,8 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     ++n->step_no;
     RET_IF(net_forward(n, frames_d, recon_d, true, op_eligible(n)));
     {
-        const int rcg = grads_grouped(n);
+        int rcg = grads_grouped(n);
+        if (rcg == AEFFT_OK) rcg = mse_flush(n);      // (a gradient route without the wgrad launch: the deferred MSE sums as their own launch after all)
         if (rcg != AEFFT_OK) { n->recon_deferred = nullptr; return rcg; }
     }
     if (n->recon_deferred) {
@@ -2325,11 +2353,21 @@ extern "C" int aefft_net_grad_buffer(aefft_net* n, float** buf_d, size_t* nfloat
     return AEFFT_OK;
 }
 
+extern "C" int aefft_net_last_mse(aefft_net* n, float* mse_d)
+{
+    if (!n || !mse_d) return AEFFT_EINVAL;
+    aefft_ctx* ctx = n->ctx;
+    RET_IF(mse_flush(n));
+    HIPCHK(ctx, hipMemcpyAsync(mse_d, n->mse_post, sizeof(float) * n->L, hipMemcpyDeviceToDevice, ctx->stream));
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int sym, float grad_scale, float* mse_d)
 {
     if (!n) return AEFFT_EINVAL;
     aefft_ctx* ctx = n->ctx;
     if (!n->have_grad) return fail(ctx, AEFFT_ESTATE, "aefft_net_step_apply: call aefft_net_step_grad first");
+    RET_IF(mse_flush(n));
     for (auto& q : n->pr) q.G_valid = false;          // the weights are about to change (the grouped path re-derives G and sets it again)
     const float del = 0.1f * del0;
     RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));

@@ -139,7 +139,9 @@ hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
 
 // ---- weight_kernels.hip ----------------------------------------------------------------
 struct WgradProb { const float *c, *f, *Q, *es, *b; float *gc, *gf; int dM, dD; float inv_den, norm; int nq; };   // Q [dD][dD][nq][T*T] (nq row-chunk partial sums, added here), es [2*dD]
-struct WgradGroup { WgradProb q[8]; int n; int start[9]; };
+struct WgradGroup { WgradProb q[8]; int n; int start[9];
+                    // nullable: the slot sums of the PREVIOUS step's post-update MSE (launch_mse_finish deferred by aefft_net_step_apply(mse_d = NULL)) as one trailing workgroup
+                    float *fin_slots, *fin_out, *fin_tail; int fin_L; float fin_scale; };
 hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st);
 
 const float2* twiddle_table();   // device address of the table uploaded by upload_twiddles()

@@ -793,25 +793,7 @@ __global__ __launch_bounds__(MSE_SLOTS) void mse_finish_kernel(float* __restrict
         for (int d = threadIdx.x; d < ba.dD; d += MSE_SLOTS) ba.beta[d] = ba.p[d] + bacc[d] / (float)ba.dD;
         return;
     }
-    for (int l = 0; l < L; ++l) {
-        float* s = slots + ((long)l * MSE_SLOTS + threadIdx.x) * MSE_SLOT_STRIDE;
-        float v = *s;
-        *s = 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t = out[l];
-            for (int w = 0; w < MSE_SLOTS / 64; ++w) t += ws[w];
-            out[l] = t;
-            if (copy) copy[l] = t;
-            // the packed buffer's tail: what the caller's all-reduce left there (the sum over ranks of the PREVIOUS step's MSEs) is kept,
-            // scaled to the global mean, in the L floats behind the tail before this step's local value takes its place
-            if (copy2) { copy2[L + l] = copy2[l] * prev_scale; copy2[l] = t; }
-        }
-        __syncthreads();
-    }
+    mse_finish_body(slots, out, copy, copy2, L, prev_scale, ws);
 }
 
 hipError_t launch_mse_finish(float* slots, float* out, float* copy, int L, hipStream_t st, const BetaArgs* ba, float* copy2, float prev_scale)

@@ -76,4 +76,29 @@ __device__ __forceinline__ void update_body(const UpdateArgs& a, int blk)
     if (blk * 256 < max(a.dM, a.dD)) update_bias_part(a, blk);        // (launch_update checks n >= dM, dD: the blocks exist)
 }
 
+// sums (and clears) the MSE slot accumulators of one step: out[l] += sum, copy[l] = out[l]; the packed buffer's tail (copy2): what the
+// caller's all-reduce left there (the sum over ranks of the PREVIOUS step's MSEs) is kept, scaled to the global mean, in the L floats
+// behind the tail before this step's local value takes its place.  One workgroup of MSE_SLOTS threads; ws: MSE_SLOTS/64 floats of LDS.
+__device__ __forceinline__ void mse_finish_body(float* __restrict__ slots, float* __restrict__ out, float* __restrict__ copy, float* __restrict__ copy2,
+                                                int L, float prev_scale, float* ws)
+{
+    for (int l = 0; l < L; ++l) {
+        float* s = slots + ((long)l * MSE_SLOTS + threadIdx.x) * MSE_SLOT_STRIDE;
+        float v = *s;
+        *s = 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = out[l];
+            for (int w = 0; w < MSE_SLOTS / 64; ++w) t += ws[w];
+            out[l] = t;
+            if (copy) copy[l] = t;
+            if (copy2) { copy2[L + l] = copy2[l] * prev_scale; copy2[l] = t; }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace aefft

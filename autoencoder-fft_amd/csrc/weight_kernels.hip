@@ -12,6 +12,7 @@
 // back per step at cfg3) never exist.  (Likewise the per-bin product G = F.C/(dM dD) used by the post-update MSE is the
 // spectrum of the (2Nk-1) x (2Nl-1) kernel sum_m f[d'][m] (*) c[m][d] / (dM dD): gspec_gbody, pruned_kernels.hip.)
 #include "internal.h"
+#include "update_device.h"
 #include <algorithm>
 
 namespace aefft {
@@ -26,6 +27,10 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
 {
     constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, SL = 8, TM = 256 / (NK * SL);    // 6 outer channels x 8 d1 slices per workgroup for 5x5 (4 slices: 18.1 us, 8: 14.2 us at cfg3)
     extern __shared__ float sh[];                       // Qs[dD][TT] | ws[dD][TM][KK] | red[256][NK]
+    if ((int)blockIdx.x == g.start[g.n]) {              // (trailing workgroup, only launched for it) the previous step's deferred MSE sums
+        mse_finish_body(g.fin_slots, g.fin_out, nullptr, g.fin_tail, g.fin_L, g.fin_scale, sh);
+        return;
+    }
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
@@ -164,8 +169,10 @@ hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
                                : hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (Nk == 3) wgrad_taps_kernel<3><<<dim3(total), 256, lds, st>>>(g);
-    else wgrad_taps_kernel<5><<<dim3(total), 256, lds, st>>>(g);
+    static_assert(MSE_SLOTS == 256, "the deferred MSE sums run as one workgroup of this launch");
+    const int extra = g.fin_slots ? 1 : 0;
+    if (Nk == 3) wgrad_taps_kernel<3><<<dim3(total + extra), 256, lds, st>>>(g);
+    else wgrad_taps_kernel<5><<<dim3(total + extra), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 

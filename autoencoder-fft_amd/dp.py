@@ -114,6 +114,7 @@ class DataParallelStep:
     def flush_mse(self):
         """global-batch post-update MSE per pair of the LAST step: one small all-reduce of the buffer's tail (end of training / logging points)"""
         import torch
+        self.net.last_mse()              # (a step_apply without an mse output leaves the sums to the next step: form them now)
         with torch.cuda.stream(self.net.ctx.torch_stream()):
             t = self.gbuf[self.tail].clone()
             scale = allreduce_sum_(t, self.group)

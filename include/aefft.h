@@ -75,7 +75,8 @@ enum {
     AEFFT_F_NOCHAIN = 1 << 17,    /* operator form: the network on the basis frames layer by layer instead of one fused launch */
     AEFFT_F_NOFUSEUPD = 1 << 18,  /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
     AEFFT_F_NOAHEAD = 1 << 19,    /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
-    AEFFT_F_NORCORR = 1 << 20     /* spatial mode: dC through the back-convolved error (a dM-plane tensor) instead of the error-input correlation R */
+    AEFFT_F_NORCORR = 1 << 20,    /* spatial mode: dC through the back-convolved error (a dM-plane tensor) instead of the error-input correlation R */
+    AEFFT_F_NOLAZYMSE = 1 << 21   /* aefft_net_step_apply(mse_d = NULL) still sums the MSE slots in a launch of its own instead of leaving them to the next step's gradient launch */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);
@@ -251,7 +252,8 @@ int aefft_net_set_input_ready(aefft_net* net, int enable);
  * 1/world, and the tail times 1/world is the global-batch MSE of the previous step (the MSE rides in the gradients' message;
  * the post-update MSE of a step needs that step's reduced gradients, so it travels one step behind).  aefft_net_step_apply reads the
  * gradient part only and overwrites the tail; what it finds there it first saves, times its grad_scale, in the L floats BEHIND the
- * buffer (buf_d[nfloats .. nfloats + L), not part of the message): after step_apply of step t+1 they hold the global-batch MSE of step t. */
+ * buffer (buf_d[nfloats .. nfloats + L), not part of the message): after step_apply of step t+1 they hold the global-batch MSE of step t
+ * (with mse_d = NULL, see aefft_net_last_mse: once the sums of step t+1 have been formed, i.e. after the next aefft_net_step_grad). */
 int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 /* Which form the NEXT aefft_net_step_grad / _apply of this net runs in (decided by the net's shapes and the development switches; the
  * arithmetic is the reference's in every form, re-associated -- DESIGN.md section 4):
@@ -266,6 +268,11 @@ int aefft_net_grad_buffer(aefft_net* net, float** buf_d, size_t* nfloats);
 enum { AEFFT_FORM_PER_FRAME = 0, AEFFT_FORM_OPERATOR = 1, AEFFT_FORM_OPERATOR_CHAIN = 2 };
 int aefft_net_step_form(aefft_net* net);
 int aefft_net_step_apply(aefft_net* net, float del0, int maxdiff, int sym, float grad_scale, float* mse_d);
+/* The per-pair post-update MSEs of the LAST aefft_net_step_apply (fft_backproplib.cu:1463), to mse_d[L] (device), in stream order.
+ * aefft_net_step_apply(mse_d = NULL) does not form them in a launch of its own: the per-workgroup partial sums wait in the net and are
+ * added up by one extra workgroup of the next aefft_net_step_grad's gradient launch -- in time for the packed buffer's MSE tail and that
+ * step's all-reduce -- or by this call, whichever comes first.  A loop that logs the MSE every K steps calls this every K steps. */
+int aefft_net_last_mse(aefft_net* net, float* mse_d);
 int aefft_net_reset_momentum(aefft_net* net);
 
 /* ---- measurement ----------------------------------------------------------------------------- */

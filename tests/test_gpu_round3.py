@@ -318,3 +318,47 @@ def test_step_apply_saves_the_reduced_mse_tail_behind_the_packed_buffer(ctx):
     assert np.allclose(host(net.mse_prev_global()), m1, rtol=1e-6)                          # global mean of step 1, saved by step 2's update half
     assert np.array_equal(host(net.grad_buffer())[-L:], m2)
     net.close()
+
+
+@pytest.mark.parametrize("path", ["", "NOOPFORM", "NOLAZYMSE"])
+def test_step_apply_without_mse_output_defers_the_sums_to_the_next_gradient_launch(ctx, flags, path):
+    """aefft_net_step_apply(mse_d = NULL) leaves the slot sums of the post-update MSE to one extra workgroup of the next step's gradient
+    launch (or to aefft_net_last_mse): weights, the packed buffer's MSE tail as the all-reduce sees it, the saved global MSE and the MSEs
+    themselves are those of the run that asks for the MSE every step -- also when a forward / layer export / burst sits in between."""
+    rng = np.random.default_rng(55)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6, 5], 5, 2, 2
+    L = len(maps)
+    ws, dD = [], D
+    for dM in maps:
+        ws.append((rng.uniform(-1, 1, (dM, dD, Nk, Nk)), rng.uniform(-1, 1, dM), rng.uniform(-1, 1, (dD, dM, Nk, Nk)), rng.uniform(-1, 1, dD))); dD = dM
+    xs = [ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N)))) for _ in range(4)]
+    res = []
+    for ask in (True, False):
+        flags(*path.split(","))
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        mse = ctx.empty(L)
+        tails, prevs, mses = [], [], []
+        for i, x in enumerate(xs):
+            net.step_grad(x, None)
+            tails.append(host(net.grad_buffer())[-L:].copy())          # what an all-reduce would carry: the previous step's MSEs
+            prevs.append(host(net.mse_prev_global()).copy())            # (saved when those sums were formed: the step before that)
+            net.step_apply(0.02, 0, 0, 1.0, mse if ask else None)
+            if i == 1:
+                net.get_layer(2)                                        # something else between two steps
+            if ask or i == len(xs) - 1:
+                if not ask:
+                    net.last_mse(mse)
+                mses.append(host(mse).copy())
+        res.append((tails, prevs, mses, [net.get_pair(l) for l in range(L)]))
+        net.close()
+    (t0, p0, m0, w0), (t1, p1, m1, w1) = res
+    for a, b in zip(t0, t1):
+        assert np.array_equal(a, b)
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(m0[-1], m1[-1]) and np.all(m0[-1] > 0)
+    for a, b in zip(w0, w1):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
