@@ -947,6 +947,7 @@ struct aefft_net {
     size_t scratch_n = 0;
     float* mse_pre = nullptr;  // = scratch
     float* mse_post = nullptr; // = scratch + L
+    float* gtaps = nullptr;      // G' from the stored taps on HBM-sized grids: the (2Nk-1)^2 taps of every plane of every pair (gprime_from_taps)
     float *gd_out = nullptr, *gd_part = nullptr;   // multiobjective mode: [cd | fd | bd | pd] per pair, and the chunk partial sums (gradient_diff_ws_floats)
     bool mse_pending = false;   // the slots hold the unsummed post-update MSE of the last aefft_net_step_apply (mse_d == NULL): summed by the next step's wgrad launch or mse_flush
     float mse_pending_scale = 1.f;
@@ -1274,13 +1275,44 @@ static int gprime_from_taps(aefft_net* n, bool* done)
     aefft_ctx* ctx = n->ctx;
     if (n->L > 8 || n->pr[0].Nk != n->pr[0].Nl || (n->pr[0].Nk != 3 && n->pr[0].Nk != 5)) return AEFFT_OK;
     PrunedGroup pg{};
+    GtapsGroup tg{};
     double bytes = 0;
+    const int TT = (2 * n->pr[0].Nk - 1) * (2 * n->pr[0].Nk - 1);
+    bool chunked = false;                                  // some plane is transformed by several row-chunk workgroups: the taps are formed once, in a launch in front
     for (int l = 0; l < n->L; ++l) {
         Pair& q = n->pr[l];
         if (q.Nk != n->pr[0].Nk || q.Nl != n->pr[0].Nk || !pruned_supported(q.Nk, q.Nl, q.Nx, q.Ny) || (double)q.dD * q.dD * q.P * 8.0 >= 4294967296.0) return AEFFT_OK;
         pg.q[l] = PrunedProb{nullptr, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f, 0, 0};
         pg.gsrc[l] = GtapSrc{q.c, q.f, q.dM, q.dD, 1.0f / ((float)q.dM * (float)q.dD)};
         bytes += (double)q.dD * q.dD * q.P * 8.0 + 2.0 * q.dM * q.dD * q.Nk * q.Nl * 4.0;
+        chunked = chunked || q.Nx > 64;
+    }
+    if (chunked) {
+        // taps once per plane, then their spectra as an ordinary pruned transform of (2Nk-1)^2-tap kernels (its own kernel instantiation:
+        // the planar-spectra launch keeps its code)
+        if (!n->gtaps) {
+            size_t nt = 0;
+            for (const Pair& q : n->pr) nt += (size_t)q.dD * q.dD * TT;
+            RET_IF(net_alloc_t(n, &n->gtaps, nt));
+        }
+        PrunedGroup pt{};
+        float* o = n->gtaps;
+        for (int l = 0; l < n->L; ++l) {
+            const Pair& q = n->pr[l];
+            tg.gs[l] = pg.gsrc[l]; tg.out[l] = o;
+            pt.q[l] = PrunedProb{o, q.G, (long)q.dD * q.dD, q.Nx, q.Ny, 1.0f, 0, 0};
+            o += (size_t)q.dD * q.dD * TT;
+        }
+        tg.n = pt.n = n->L;
+        hipError_t e;
+        {
+            Bracket br(ctx, KID_KSPEC, bytes);
+            e = launch_gtaps_group(tg, n->pr[0].Nk, ctx->cur);
+            if (e == hipSuccess) e = launch_kspec_group_taps(pt, ctx->tw, 2 * n->pr[0].Nk - 1, ctx->cur);
+        }
+        if (e == hipSuccess) { *done = true; return AEFFT_OK; }
+        if (e != hipErrorInvalidValue) return fail(ctx, AEFFT_EHIP, "G'(stored taps)", e);
+        (void)hipGetLastError();                           // (shapes these launches do not serve: taps formed in the transforming workgroups, below)
     }
     pg.n = n->L;
     hipError_t e;

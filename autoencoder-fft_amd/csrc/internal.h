@@ -116,6 +116,13 @@ struct PrunedProb { const void* src; void* dst; long planes; int Nx, Ny; float s
 // forward transform only: the problem's planes are G' = F'.C'/(dM dD) [dD][dD] of a pair, their (2Nk-1)^2 taps formed inside the launch from
 // c | f (read through the problem's TapUpd); f == null: an ordinary problem (taps at PrunedProb::src)
 struct GtapSrc { const float* c; const float* f; int dM, dD; float scale; };
+// the taps of G' = F.C / (dM dD) of up to 8 pairs, [dD*dD][(2Nk-1)^2] each, in one launch (HBM-sized grids: every plane is transformed by several
+// row-chunk workgroups, which would each form the same taps again -- 238 of the 538 us of the G' launch at cfg3-P1); their spectra are then an
+// ordinary pruned transform of (2Nk-1)^2-tap kernels: launch_kspec_group_taps
+struct GtapsGroup { GtapSrc gs[8]; float* out[8]; int n; int start[9]; };
+hipError_t launch_gtaps_group(GtapsGroup& g, int Nk, hipStream_t st);
+struct PrunedGroup;
+hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st);      // spectra of stored T x T-tap kernels, T = 5 or 9
 // forward pruned transform only: the taps are read THROUGH the pending clipped-momentum update (w - clip_step(g*gscale, D)), which
 // another launch stores afterwards (update_device.h) -- g == null: taps as stored
 struct TapUpd { const float* g; const float* D; float del, alpha, gscale; };

@@ -625,6 +625,47 @@ static hipError_t run_kgrad(const float2* D, float* g, float* part, const float2
     return hipGetLastError();
 }
 
+// the taps of G' for every plane (d', d) of the group's pairs: one workgroup per plane, gtaps_stage, stored [plane][T*T]
+template <int NK>
+__global__ __launch_bounds__(320) void gtaps_group_kernel(const GtapsGroup g)
+{
+    constexpr int T = 2 * NK - 1, TT = T * T;
+    extern __shared__ float gt_lds[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    const GtapSrc& gs = g.gs[p];
+    const int lin = blockIdx.x - g.start[p];
+    const int dp = lin / gs.dD, d0 = lin - dp * gs.dD;
+    float* taps_s = gt_lds;
+    float* work = gt_lds + TT;
+    const TapUpd none{};
+    gtaps_stage<NK>(gs, none, dp, d0, 1, taps_s, work);
+    __syncthreads();
+    for (int t = threadIdx.x; t < TT; t += blockDim.x) g.out[p][(long)lin * TT + t] = taps_s[t];
+}
+
+hipError_t launch_gtaps_group(GtapsGroup& g, int Nk, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8 || (Nk != 3 && Nk != 5)) return hipErrorInvalidValue;
+    const int T = 2 * Nk - 1;
+    int total = 0; size_t lds = 0;
+    for (int i = 0; i < g.n; ++i) {
+        g.start[i] = total; total += g.gs[i].dD * g.gs[i].dD;
+        lds = std::max(lds, sizeof(float) * ((size_t)T * T + std::max((size_t)(g.gs[i].dM * Nk * Nk + 1) * 2, (size_t)320 * T)));
+    }
+    g.start[g.n] = total;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        const hipError_t e = Nk == 3 ? hipFuncSetAttribute(reinterpret_cast<const void*>(gtaps_group_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                     : hipFuncSetAttribute(reinterpret_cast<const void*>(gtaps_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (Nk == 3) gtaps_group_kernel<3><<<dim3(total), 320, lds, st>>>(g);
+    else gtaps_group_kernel<5><<<dim3(total), 320, lds, st>>>(g);
+    return hipGetLastError();
+}
+
 static PackArgs g_pack_none{};
 static BiasUpdGroup g_bu_none{};
 template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, const float2* tw, hipStream_t st, PackArgs* pk = nullptr, const BiasUpdGroup* bu = nullptr)
@@ -772,6 +813,16 @@ hipError_t launch_kspec_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, 
     if (Nk == 3) return run_kspec_group<3, 3>(g, tw, st, packed, bias_upd);
     if (Nk == 5) return run_kspec_group<5, 5>(g, tw, st, packed, bias_upd);
     return run_kspec_group<7, 7>(g, tw, st, nullptr, bias_upd);
+}
+
+hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st)
+{
+    if (g.n < 1 || g.n > 8 || !tw || (T != 5 && T != 9)) return hipErrorInvalidValue;
+    for (int p = 0; p < g.n; ++p) {
+        const PrunedProb& q = g.q[p];
+        if (q.planes <= 0 || g.gsrc[p].f || q.Nx > TW_N || q.Ny > TW_N || (TW_N % q.Nx) || (TW_N % q.Ny) || q.Ny / 2 + 1 > 320 || T > q.Nx || T > q.Ny) return hipErrorInvalidValue;
+    }
+    return T == 5 ? run_kspec_group<5, 5>(g, tw, st) : run_kspec_group<9, 9>(g, tw, st);
 }
 
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)

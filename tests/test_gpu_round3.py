@@ -120,6 +120,14 @@ def test_gprime_from_taps_with_many_channels(ctx, flags, path):
     _step_vs_oracle(ctx, np.random.default_rng(5), 2, 3, 64, 64, [32, 40, 8], 5, 2)
 
 
+@pytest.mark.parametrize("path", ["NOOPFORM,GTAPS", "NOCHAIN,NOFUSEUPD,GTAPS"])
+def test_gprime_taps_formed_once_for_row_chunked_planes(ctx, flags, path):
+    """... on grids of more than 64 rows, where a plane of G' is transformed by several row-chunk workgroups and its (2Nk-1)^2 taps come from
+    a launch in front (gtaps_group_kernel) instead of being formed again by each of them: two pairs on a 128 x 128 grid (no pooling)."""
+    flags(*path.split(","))
+    _step_vs_oracle(ctx, np.random.default_rng(6), 2, 3, 128, 128, [6, 10], 5, 1)
+
+
 def _small_net(ctx, rng, D=3, N=64, maps=(4, 6, 5), Nk=5, s=2, B=3):
     net = aefft.Net(ctx, D, N, N, list(maps), Nk, s, batch=B)
     dD = D
