@@ -730,7 +730,7 @@ static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
     // few planes on a large grid (the outermost pair of a 1024^2 net: 9 planes of 512 x 257 bins): 8 chunks are 72 workgroups of 64
     // serial rows each -- the launch's critical path; up to 32 chunks while the problem stays below ~1000 workgroups
     const long pb = (planes + o.ppb - 1) / o.ppb;
-    const int cap = std::min(pb * 8 >= 1024 ? 8 : KG_MAXCHUNKS, max_chunks);
+    const int cap = std::min(pb * 8 >= 1024 ? 8 : KG_MAXCHUNKS, max_chunks);      // (the launcher passes max_chunks <= 8 when the LAUNCH is large: run_kgrad_group)
     if (cap > 1 && o.RB > 16) {
         // one 16-row load batch per slice and chunk while the destination has room for the chunks' partial sums
         int cr = 16 * o.S;
@@ -749,11 +749,16 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
 {
     constexpr int NT = KG_NT;
     int total = 0; size_t lds = 0;
+    // more than 8 row chunks only where a problem's 64-row workgroups would be the stragglers of a SMALL launch (cfg5's outermost pair);
+    // in a launch of thousands of equally long workgroups (cfg3-P1: every pair on the 512^2 grid) they only add partial sums: 411 -> 456 us
+    long total8 = 0;
+    for (int p = 0; p < g.n; ++p) { const KgGeom k8 = kgrad_group_geom(g.q[p].planes, g.q[p].Nx, g.q[p].Ny, std::min(8, std::max(1, g.chunks[p]))); total8 += (long)k8.pblocks * k8.chunks; }
+    const int launch_cap = total8 < 2048 ? KG_MAXCHUNKS : 8;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         const int Nyr = q.Ny / 2 + 1;
         if (Nyr > NT) return hipErrorInvalidValue;
-        const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::max(1, g.chunks[p]));     // in: room at dst; out: chunks used
+        const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::min(launch_cap, std::max(1, g.chunks[p])));     // in: room at dst; out: chunks used
         g.ppb[p] = k.ppb; g.rows[p] = k.S; g.rb[p] = k.RB; g.chunks[p] = k.chunks; g.pblocks[p] = k.pblocks;
         g.start[p] = total; total += k.pblocks * k.chunks;
         lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)std::max(NT, k.ppb * NK * NL)));
