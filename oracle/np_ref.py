@@ -289,6 +289,42 @@ def gradient_diff(c, f, b, p, dtype=np.float64):
     return cd, fd, bd, pd
 
 
+def gradient_diff_fast(c, f, b, p, block=64):
+    """fft.cu:709-753 in float64, vectorised: the SAME sums as `gradient_diff` (which follows the source loop by loop) with the
+    partner loop as array arithmetic, so that config 5's map counts (64 -> 128: 8192 kernels, 6.7e7 kernel pairs) run in seconds:
+        g[i] = sum_{j: m_j != m_i and d_j != d_i} (K_i - K_j) / |K_i - K_j|^2  =  K_i * sum_j w_ij - sum_j w_ij K_j,
+    w_ij = mask_ij / |K_i - K_j|^2 with the squared distances formed from the differences themselves (no |a|^2+|b|^2-2ab
+    cancellation).  Checked against the literal loop nest in tests/test_oracle_fast.py.  Coinciding kernels give inf/nan as in
+    the source (`:724-746`).  Returns (cd, fd, bd, pd) like gradient_diff."""
+    c = np.asarray(c, np.float64); f = np.asarray(f, np.float64)
+    b = np.asarray(b, np.float64); p = np.asarray(p, np.float64)
+    dM, dD = c.shape[:2]
+
+    def one(K):                                   # K [dM][dD][Nk][Nl] indexed [m][d]
+        n = dM * dD
+        Kf = K.reshape(n, -1)
+        mi = np.repeat(np.arange(dM), dD); di = np.tile(np.arange(dD), dM)
+        out = np.zeros_like(Kf)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for i0 in range(0, n, block):
+                i1 = min(n, i0 + block)
+                diff = Kf[i0:i1, None, :] - Kf[None, :, :]                       # [bi][n][T]
+                dist = np.einsum("ijt,ijt->ij", diff, diff)
+                mask = (mi[i0:i1, None] != mi[None, :]) & (di[i0:i1, None] != di[None, :])
+                w = np.where(mask, 1.0 / np.where(mask, dist, 1.0), 0.0)
+                w = np.where(mask & (dist == 0.0), np.inf, w)
+                out[i0:i1] = Kf[i0:i1] * w.sum(axis=1)[:, None] - w @ Kf
+        return out.reshape(K.shape)
+
+    cd = one(c)
+    fd = np.transpose(one(np.transpose(f, (1, 0, 2, 3))), (1, 0, 2, 3)).copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        db_ = b[:, None] - b[None, :]; np.fill_diagonal(db_, np.inf)
+        dp_ = p[:, None] - p[None, :]; np.fill_diagonal(dp_, np.inf)
+        bd = (1.0 / db_).sum(axis=1); pd = (1.0 / dp_).sum(axis=1)
+    return cd, fd, bd, pd
+
+
 def backprop_double(c, f, b, p, dck, dfk, db, dp, Dc, Df, Db, Dp, cd, fd, bd, pd, dele, dtype=np.float64):
     """fft.cu:657-704: g = w0*g_rec - w1*g_diff then the backprop_d rule."""
     w0, w1 = dtype(W0), dtype(W1)
@@ -431,3 +467,44 @@ def backprop_sym(c, f, b, p, dck, dfk, db, dp, Dc, Df, Db, Dp, dele, cd=None, fd
     Db = _clip_step(gb, Db, dele, dtype); b = (b - Db).astype(dtype)
     Dp = _clip_step(gp, Dp, dele, dtype); p = (p - Dp).astype(dtype)
     return c, f, b, p, Dc, Df, Db, Dp
+
+
+# ----------------------------------------------------------------------------------------
+# the build-defined training step over a whole network (SURVEY 8d "one frame fwd+bwd", 8e): autoenc_fft of every frame, then for
+# EVERY pair one backprop_fft loop-body iteration on the spectra of that forward (batch-mean gradients), momentum carried from
+# step to step (aefft_net_step_grad / _apply).  Used by the trajectory tests; one call = one step.
+# ----------------------------------------------------------------------------------------
+def net_step(xs, ws, moms, scale, del0, maxdiff=0, sym=0, dtype=np.float64, fast_diff=True):
+    """xs [B][D][Nx][Ny]; ws = [(c, b, f, p)] per pair; moms = [(Dc, Df, Db, Dp)] per pair (None: zeros).  Returns
+    (ws', moms', mse per pair [post-update, fft.cu:1463], recon [B][D][Nx][Ny])."""
+    L = len(ws)
+    net_c = [np.asarray(w[0], dtype) for w in ws] + [np.asarray(w[2], dtype) for w in ws[::-1]]
+    net_b = [np.asarray(w[1], dtype) for w in ws] + [np.asarray(w[3], dtype) for w in ws[::-1]]
+    cf = None
+    sp = []
+    for x in xs:
+        layers, cf, spec = autoenc_fft(np.asarray(x, dtype), net_c, net_b, [scale] * L + [-scale] * L, net_cfreq=cf, dtype=dtype)
+        sp.append((layers, spec))
+    recon = np.stack([q[0][-1] for q in sp])
+    dele = dtype(0.1) * dtype(del0)
+    out_w, out_m, mses = [], [], []
+    for l in range(L):
+        c, b, f, p = (np.asarray(a, dtype) for a in ws[l])
+        mom = moms[l] if moms is not None and moms[l] is not None else tuple(np.zeros_like(a) for a in (c, f, b, p))
+        Xs = [q[1][2 * l + 1] for q in sp]; Os = [q[1][4 * L - 1 - 2 * l] for q in sp]
+        dM, dD, Nk, Nl = c.shape
+        Nx = Xs[0].shape[-2]; Ny = (Xs[0].shape[-1] - 1) * 2
+        if not sym:
+            r = batch_train_iter(Xs, Xs, Os, cf[l], cf[2 * L - 1 - l], c, f, b, p, mom, dele, maxdiff, dtype)
+            out_w.append((r["c"], r["b"], r["f"], r["p"])); out_m.append(r["mom"]); mses.append(r["mse"])
+            continue
+        dck, dfk, db, dp = batch_grad(Xs, Xs, Os, cf[l], cf[2 * L - 1 - l], b, Nk, Nl, dtype)
+        extra = ()
+        if maxdiff:
+            extra = tuple(np.asarray(a, dtype) for a in (gradient_diff_fast(c, f, b, p) if fast_diff else gradient_diff(c, f, b, p, dtype)))
+        c2, f2, b2, p2, Dc, Df, Db, Dp = backprop_sym(c, f, b, p, dck, dfk, db, dp, *mom, dele, *extra, dtype=dtype)
+        C = fft(pad_k(c2, Nx, Ny), dtype); F = fft(pad_k(f2, Nx, Ny), dtype)
+        Os2 = [conv_k(conv_k(X, C, b2, Nx, Ny, dtype), F, p2, Nx, Ny, dtype) for X in Xs]
+        mses.append(dtype(np.mean([mse_fft(X, O, dM, dD, Nx, Ny, dtype) for X, O in zip(Xs, Os2)])))
+        out_w.append((c2, b2, f2, p2)); out_m.append((Dc, Df, Db, Dp))
+    return out_w, out_m, mses, recon

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- not product code.
 //
-// C-callable wrapper around the reference's OWN CPU functions (Conv, backprop, Pool, Portion;
-// /root/reference/source/netlib.cpp:114-164,292-451), which oracle/Makefile compiles from the
+// C-callable wrapper around the reference's OWN CPU functions (Conv, backprop, Pool, Portion, Init_conv, SaveLoad_conv, LoadParam;
+// /root/reference/source/netlib.cpp:114-451), which oracle/Makefile compiles from the
 // reference sources where they lie (nothing is copied into this repo; see the Makefile for the
 // exact recipe).  The wrapper only marshals flat float arrays into the nested std::vector
 // arguments those functions take.  It is linked into oracle/_ref/libnetlib_ref.so, used to
@@ -20,6 +20,10 @@ void Pool(V3& in, V3& out, int scale);
 void Portion(V3& in, V3& hin, V3& out, V3& in_s, V3& hin_s, V3& out_s, int q);
 void Conv(V3& in, V3& out, V4& c, V1& b);
 void backprop(V3& in, V3& out, V3& hin, V4& c, V1& b, V4& f, V1& p, float del);
+// netlib.h:14,16,18
+void Init_conv(V4& c, V1& b, int mS, int dD, int kS, int lS, float max);
+void SaveLoad_conv(V4& c, V1& b, int scale, int L, int io, int write);
+void LoadParam(int& dM, int& Lk, int& Ll, int& scal, float& rmax);
 
 static V3 to3(const float* a, int A, int B, int C) {
     V3 v(A, V2(B, V1(C)));
@@ -75,5 +79,22 @@ void ref_portion(const float* in, float* in_s, int ch, int Nx, int Ny, int q) {
     Portion(vin, dummy_h, vin, vs, vhs, vos, q);
     from3(vs, in_s);
 }
+
+// netlib.cpp:166-197: weights drawn from the C library's rand() stream (the caller seeds it with srand)
+void ref_init_conv(float* c, float* b, int mS, int dD, int kS, int lS, float max) {
+    V4 vc; V1 vb;
+    Init_conv(vc, vb, mS, dD, kS, lS, max);
+    from4(vc, c);
+    for (int m = 0; m < mS; m++) b[m] = vb[m];
+}
+// netlib.cpp:220-272: ./weights/C_weights_<L><_in|_out>_D=.._M=.._Lk=.._Ll=.._S=...conv relative to the working directory
+void ref_saveload_conv(float* c, float* b, int dM, int dD, int Nk, int Nl, int scale, int L, int io, int write) {
+    V4 vc = to4(c, dM, dD, Nk, Nl); V1 vb(b, b + dM);
+    SaveLoad_conv(vc, vb, scale, L, io, write);
+    from4(vc, c);
+    for (int m = 0; m < dM; m++) b[m] = vb[m];
+}
+// netlib.cpp:274-289: New_Layer_Param.txt in the working directory
+void ref_load_param(int* dM, int* Lk, int* Ll, int* scal, float* rmax) { LoadParam(*dM, *Lk, *Ll, *scal, *rmax); }
 
 }  // extern "C"

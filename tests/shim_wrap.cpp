@@ -40,6 +40,20 @@ void w_portion(const float* in, float* in_s, int ch, int Nx, int Ny, int q) {
     Maps vin = to3(in, ch, Nx, Ny), h = to3(in, 1, Nx, Ny), vs(ch, Plane(Nx / q, Bias(Ny / q))), vo = vs, vh(1, Plane(Nx / q, Bias(Ny / q)));
     Portion(vin, h, vin, vs, vh, vo, q); from3(vs, in_s);
 }
+// Init_conv / SaveLoad_conv / LoadParam (netlib.h:14,16,18) through the product's exports
+void w_init_conv(float* c, float* b, int mS, int dD, int kS, int lS, float max) {
+    Kernels vc; Bias vb;
+    Init_conv(vc, vb, mS, dD, kS, lS, max);
+    from4(vc, c);
+    for (int m = 0; m < mS; m++) b[m] = vb[m];
+}
+void w_saveload_conv(float* c, float* b, int dM, int dD, int Nk, int Nl, int scale, int L, int io, int write) {
+    Kernels vc = to4(c, dM, dD, Nk, Nl); Bias vb(b, b + dM);
+    SaveLoad_conv(vc, vb, scale, L, io, write);
+    from4(vc, c);
+    for (int m = 0; m < dM; m++) b[m] = vb[m];
+}
+void w_load_param(int* dM, int* Lk, int* Ll, int* scal, float* rmax) { LoadParam(*dM, *Lk, *Ll, *scal, *rmax); }
 // backprop_gpu / backprop_gpu_cc: all weight-shaped arrays in/out
 void w_backprop_gpu(const float* in, const float* out, const float* hin, float* c, float* b, float* f, float* p, float* dc, float* db, float* df,
                     float* dp, float* ddc, float* ddb, float* ddf, float* ddp, float delmax, float alpha, int tied,

@@ -55,7 +55,7 @@ def wrap():
         subprocess.run(["g++", "-O2", "-std=c++11", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
                         "-L" + libdir, "-laefft", "-Wl,-rpath," + libdir], check=True)
     L = C.CDLL(out)
-    for n in ("w_conv", "w_backprop_cpu", "w_pool", "w_portion", "w_backprop_gpu", "w_fft_pair"):
+    for n in ("w_conv", "w_backprop_cpu", "w_pool", "w_portion", "w_backprop_gpu", "w_fft_pair", "w_init_conv", "w_saveload_conv", "w_load_param"):
         getattr(L, n).restype = None
     return L
 
@@ -106,6 +106,101 @@ def test_host_functions_bit_identical_to_compiled_reference(wrap):
         ps = np.zeros((dD, N // 2, N // 2), np.float32)
         wrap.w_portion(_p(x), _p(ps), dD, N, N, 2)
         assert np.array_equal(ps, ref.portion(x, 2))
+
+
+@pytest.mark.parametrize("tag,dD,dM,N,Nk", [("cfg1", 1, 4, 128, 3), ("k5", 2, 3, 20, 5)])
+def test_config1_golden_vectors_through_the_product_host_functions(wrap, tag, dD, dM, N, Nk):
+    """BASELINE configs[0] (128x128 gray, 4 maps, 3x3, spatial mode, CPU path) through the PRODUCT's host functions -- the
+    `Pool`, `Conv`, `Portion`, `backprop` that libaefft.so exports under the reference's manglings (shims.cpp; reference:
+    netlib.cpp:114-164, 292-315, 318-451) -- in the application's call order Pool(1) -> Conv -> Conv -> Pool(-1) -> Portion(q=1)
+    -> backprop(del=0.2) (autoencoder.cpp:135-150,165-182), against tests/golden/cpu_path.npz, whose outputs come from the
+    reference's own compiled code (tests/golden/make_golden.py).  Bit-exact: float32 host arithmetic in the reference's loop order."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cpu_path.npz"))
+    x, c, b, f, p = (np.ascontiguousarray(g[f"{tag}_{k}"]) for k in ("x", "c", "b", "f", "p"))
+    assert x.shape == (dD, N, N) and c.shape == (dM, dD, Nk, Nk)
+    pin = np.zeros_like(x)
+    wrap.w_pool(_p(x), _p(pin), dD, N, N, N, N, 1)                       # Pool(+1): the int-truncating maximum (SURVEY B-16)
+    h = np.zeros((dM, N, N), np.float32)
+    wrap.w_conv(_p(pin), _p(h), _p(c), _p(b), dD, dM, N, N, Nk, Nk, 0)
+    assert np.array_equal(h, g[f"{tag}_h"])
+    o = np.zeros((dD, N, N), np.float32)
+    wrap.w_conv(_p(h), _p(o), _p(f), _p(p), dM, dD, N, N, Nk, Nk, 0)
+    assert np.array_equal(o, g[f"{tag}_o"])
+    up = np.zeros_like(o)
+    wrap.w_pool(_p(o), _p(up), dD, N, N, N, N, -1)                       # Pool(-1): nearest-neighbour up-sampling by 1
+    assert np.array_equal(up, o)
+    ps = np.zeros_like(pin)
+    wrap.w_portion(_p(pin), _p(ps), dD, N, N, 1)                         # Portion(q = 1): the whole plane
+    assert np.array_equal(ps, pin)
+    c2, b2, f2, p2 = c.copy(), b.copy(), f.copy(), p.copy()
+    wrap.w_backprop_cpu(_p(ps), _p(up), _p(h), _p(c2), _p(b2), _p(f2), _p(p2), C.c_float(0.2), dD, dM, N, N, Nk, Nk)
+    for a, k in ((c2, "c2"), (b2, "b2"), (f2, "f2"), (p2, "p2")):
+        assert np.array_equal(a, g[f"{tag}_{k}"]), k
+    assert np.abs(c2 - c).max() > 0
+
+
+def _ref_lib():
+    ref = cpu.reference()
+    if ref is None or not hasattr(ref.lib, "ref_init_conv"):
+        pytest.skip("oracle/_ref not built (or built from the older recipe)")
+    for n in ("ref_init_conv", "ref_saveload_conv", "ref_load_param"):
+        getattr(ref.lib, n).restype = None
+    return ref.lib
+
+
+def test_init_conv_draws_the_reference_rand_stream(wrap):
+    """`Init_conv` (netlib.cpp:166-197): weights U(-max, max) drawn from the C library's rand() in the order m, d, k, l, then the
+    bias of map m.  Same srand seed -> the product's export and the reference's compiled function return the same bits."""
+    R_ = _ref_lib()
+    libc = C.CDLL(None)
+    for seed, (mS, dD, kS, lS, mx) in enumerate(((4, 3, 5, 5, 3.0), (10, 1, 3, 3, 1.0), (2, 7, 3, 5, 0.25))):
+        cr = np.zeros((mS, dD, kS, lS), np.float32); br = np.zeros(mS, np.float32)
+        cp, bp = np.zeros_like(cr), np.zeros_like(br)
+        libc.srand(1234 + seed); R_.ref_init_conv(_p(cr), _p(br), mS, dD, kS, lS, C.c_float(mx))
+        libc.srand(1234 + seed); wrap.w_init_conv(_p(cp), _p(bp), mS, dD, kS, lS, C.c_float(mx))
+        assert np.array_equal(cr, cp) and np.array_equal(br, bp)
+        assert np.abs(cr).max() <= mx and np.abs(cr).max() > 0.5 * mx
+
+
+def test_weight_files_and_layer_parameters_against_the_compiled_reference(wrap, tmp_path, capfd):
+    """`SaveLoad_conv` (netlib.cpp:220-272) and `LoadParam` (:274-289): file NAMES (./weights/C_weights_<L>_<in|out>_D=_M=_Lk=_Ll=_S=.conv)
+    and BYTES written by the product == the reference's; each side loads the file the other wrote; New_Layer_Param.txt parsed alike."""
+    R_ = _ref_lib()
+    rng = np.random.default_rng(31)
+    cwd = os.getcwd()
+    dirs = {k: tmp_path / k for k in ("ref", "prod")}
+    try:
+        for dM, dD, Nk, Nl, scale, L, io in ((4, 3, 5, 5, 2, 0, 0), (3, 4, 5, 5, -2, 0, 1), (10, 1, 3, 7, 1, 3, 0)):
+            c = rng.uniform(-3, 3, (dM, dD, Nk, Nl)).astype(np.float32); b = rng.uniform(-3, 3, dM).astype(np.float32)
+            for k, fn in (("ref", R_.ref_saveload_conv), ("prod", wrap.w_saveload_conv)):
+                (dirs[k] / "weights").mkdir(parents=True, exist_ok=True)
+                os.chdir(dirs[k])
+                fn(_p(c.copy()), _p(b.copy()), dM, dD, Nk, Nl, scale, L, io, 1)
+            files = {k: sorted(os.listdir(dirs[k] / "weights")) for k in dirs}
+            assert files["ref"] == files["prod"]
+            name = f"C_weights_{L}_{'in' if io == 0 else 'out'}_D={dD}_M={dM}_Lk={(Nk - 1) // 2 - 1}_Ll={(Nl - 1) // 2 - 1}_S={scale}.conv"
+            assert name in files["ref"]
+            raw = {k: (dirs[k] / "weights" / name).read_bytes() for k in dirs}
+            assert raw["ref"] == raw["prod"] and len(raw["ref"]) == 4 * (c.size + dM)
+            assert np.array_equal(np.frombuffer(raw["ref"], np.float32), np.concatenate([c.ravel(), b]))
+            # cross-load: the product reads the reference's file, the reference reads the product's
+            for k, fn in (("ref", wrap.w_saveload_conv), ("prod", R_.ref_saveload_conv)):
+                os.chdir(dirs[k])
+                c2 = np.zeros_like(c); b2 = np.zeros_like(b)
+                fn(_p(c2), _p(b2), dM, dD, Nk, Nl, scale, L, io, 0)
+                assert np.array_equal(c2, c) and np.array_equal(b2, b)
+        # LoadParam: the shipped file's format (name value per line; values: maps, Lk, Ll, pooling scale, rmax)
+        os.chdir(dirs["ref"])
+        (dirs["ref"] / "New_Layer_Param.txt").write_text("Layer_depth 10\nKernel_L_x 1\nKernel_L_y 0\nPooling_scale 2\nMax_Rand_Init 3.5\n")
+        got = {}
+        for k, fn in (("ref", R_.ref_load_param), ("prod", wrap.w_load_param)):
+            iv = [C.c_int(-1) for _ in range(4)]; fv = C.c_float(-1)
+            fn(*[C.byref(v) for v in iv], C.byref(fv))
+            got[k] = [v.value for v in iv] + [fv.value]
+        assert got["ref"] == got["prod"] == [10, 1, 0, 2, 3.5]
+    finally:
+        os.chdir(cwd)
+    capfd.readouterr()      # (both sides print "path ..." lines, netlib.cpp:235)
 
 
 @pytest.mark.gpu
