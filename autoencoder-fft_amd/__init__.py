@@ -65,6 +65,8 @@ SIGNATURES = {
     "aefft_backprop_spatial": (_i, [_vp] + [_fp] * 15 + [_i] * 7 + [_f, _f, _i, _i]),
     "aefft_net_create": (_i, [_vp, C.POINTER(NetDesc), C.POINTER(_vp)]),
     "aefft_net_destroy": (None, [_vp]),
+    "aefft_net_npairs": (_i, [_vp]),
+    "aefft_net_pair_shape": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "aefft_net_set_pair": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "aefft_net_get_pair": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "aefft_net_pair_spectra": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -104,6 +106,39 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+DP_LIB_PATH = os.path.join(_HERE, "libaefft_dp.so")
+_dp_lib = None
+# include/aefft_dp.h (libaefft_dp.so = libaefft.so + librccl): name -> (restype, argtypes)
+DP_SIGNATURES = {
+    "aefft_dp_unique_id": (_i, [_vp]),
+    "aefft_dp_create": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "aefft_dp_destroy": (None, [_vp]),
+    "aefft_dp_last_error": (C.c_char_p, [_vp]),
+    "aefft_dp_step": (_i, [_vp, _fp, _fp, _f, _i, _i, _fp]),
+    "aefft_dp_run": (_i, [_vp, _fp, _fp, _f, _i, _i, _i]),
+    "aefft_dp_profile": (_i, [_vp, _fp, _fp, _f, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "aefft_dp_flush_mse": (_i, [_vp, _vp]),
+    "aefft_dp_allreduce_bytes": (C.c_size_t, [_vp]),
+    "aefft_dp_replicas_agree": (_i, [_vp]),
+}
+DP_ID_BYTES = 128
+
+
+def dp_lib():
+    """Load libaefft_dp.so (the data-parallel step over RCCL, include/aefft_dp.h); raises if it was not built."""
+    global _dp_lib
+    if _dp_lib is None:
+        lib()                                             # libaefft.so first: the same image the nets were created from
+        if not os.path.exists(DP_LIB_PATH):
+            raise AefftError(f"{DP_LIB_PATH} not built: run `make -C autoencoder-fft_amd/csrc dp` (__graft_entry__.build does)")
+        L = C.CDLL(DP_LIB_PATH)
+        for name, (res, args) in DP_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _dp_lib = L
+    return _dp_lib
 
 
 _exiting = False

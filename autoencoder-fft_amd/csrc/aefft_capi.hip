@@ -1107,6 +1107,18 @@ extern "C" int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* d, aefft_n
     return aefft_net_reset_momentum(n);
 }
 
+extern "C" int aefft_net_npairs(aefft_net* n) { return n ? n->L : -1; }
+extern "C" int aefft_net_pair_shape(aefft_net* n, int l, int* dD, int* dM, int* Nk, int* Nl)
+{
+    if (!n || l < 0 || l >= n->L) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_pair_shape: bad pair index");
+    const Pair& q = n->pr[l];
+    if (dD) *dD = q.dD;
+    if (dM) *dM = q.dM;
+    if (Nk) *Nk = q.Nk;
+    if (Nl) *Nl = q.Nl;
+    return AEFFT_OK;
+}
+
 extern "C" int aefft_net_reset_momentum(aefft_net* n)
 {
     if (!n) return AEFFT_EINVAL;

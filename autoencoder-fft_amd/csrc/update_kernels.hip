@@ -275,11 +275,16 @@ __global__ __launch_bounds__(256) void gradient_diff_kernel(const float* __restr
     if (m == 0 && r == 0) pd[d] = sp;
 }
 
-// partner chunk and chunk count of the launch for dM*dD kernels
-static void gdiff_geom(long np, int* chunk, int* nchunks)
+// partner chunk and chunk count of the launch for dM*dD kernels of kl taps: at most 32 chunks while the chunk's taps fit in 64 KB of LDS
+// (5x5: 512 partners); beyond that (dM*dD > 16384 at 5x5) the chunk stays at the cap and the chunk count grows -- the finish kernel adds any
+// number of partial sums in chunk order
+static void gdiff_geom(long np, int kl, int* chunk, int* nchunks)
 {
+    const int pitch = (kl + 3) & ~3;
+    int cap = 128;
+    while ((size_t)cap * 2 * pitch * sizeof(float) <= 64 * 1024) cap *= 2;
     int ch = 128;
-    while ((np + ch - 1) / ch > 32) ch *= 2;
+    while ((np + ch - 1) / ch > 32 && ch < cap) ch *= 2;
     *chunk = ch; *nchunks = (int)((np + ch - 1) / ch);
 }
 
@@ -287,8 +292,8 @@ size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl)
 {
     const long np = (long)dM * dD;
     int chunk, nchunks;
-    gdiff_geom(np, &chunk, &nchunks);
     const int kl = Nk * Nl;
+    gdiff_geom(np, kl, &chunk, &nchunks);
     if (kl != 9 && kl != 25 && kl != 49) return (size_t)2 * np * np;      // (the generic kernels' distance matrix)
     return (size_t)2 * nchunks * np * kl;
 }
@@ -306,7 +311,7 @@ hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, 
         return hipGetLastError();
     }
     int chunk, nchunks;
-    gdiff_geom(np, &chunk, &nchunks);
+    gdiff_geom(np, kl, &chunk, &nchunks);
     const dim3 grid((unsigned)((np + 255) / 256), (unsigned)nchunks, 2);
     const size_t lds = sizeof(float) * (size_t)chunk * ((kl + 3) & ~3);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -330,7 +335,7 @@ hipError_t launch_gradient_diff_group(GdiffGroup& g, int Nk, int Nl, hipStream_t
     for (int i = 0; i < g.n; ++i) {
         GdiffProb& q = g.q[i];
         const long np = (long)q.dM * q.dD;
-        gdiff_geom(np, &q.chunk, &q.nchunks);
+        gdiff_geom(np, kl, &q.chunk, &q.nchunks);
         g.start[i] = (int)total; total += ((np + 255) / 256) * q.nchunks * 2;
         g.fstart[i] = (int)ftotal; ftotal += (2 * np * kl + q.dM + q.dD + 255) / 256;
         lds = std::max(lds, sizeof(float) * (size_t)q.chunk * ((kl + 3) & ~3));

@@ -142,3 +142,74 @@ class DataParallelStep:
         gathered = [torch.empty_like(t) for _ in range(dist.get_world_size(self.group))]
         dist.all_gather(gathered, t, group=self.group)
         return all(bool((g == gathered[0]).all()) for g in gathered)
+
+
+class RcclStep:
+    """The same step with NOTHING of Python or torch.distributed between its two halves: libaefft_dp.so (include/aefft_dp.h) enqueues
+    step_grad -> ncclAllReduce on the library's stream -> step_apply(1/world) in one C call.  The ncclUniqueId reaches the other ranks
+    through `bcast` (a callable taking and returning a uint8 torch tensor of DP_ID_BYTES: e.g. a torch.distributed.broadcast from rank 0
+    on whatever group the host already has); world = 1 needs none."""
+
+    def __init__(self, net, rank=0, world=1, bcast=None):
+        import ctypes as C
+        import importlib
+        import torch
+        aefft = importlib.import_module(__package__)
+        self.L = aefft.dp_lib()
+        self.net, self.rank, self.world = net, rank, world
+        idbuf = torch.zeros(aefft.DP_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            rc = self.L.aefft_dp_unique_id(C.c_void_p(idbuf.data_ptr()))
+            if rc != 0:
+                raise aefft.AefftError(f"aefft_dp_unique_id failed with code {rc}")
+        if world > 1:
+            assert bcast is not None, "world > 1: the unique id must be broadcast from rank 0"
+            idbuf = bcast(idbuf).cpu().contiguous()
+        h = C.c_void_p()
+        rc = self.L.aefft_dp_create(net.h, net.ctx.h, rank, world, C.c_void_p(idbuf.data_ptr()), C.byref(h))
+        if rc != 0:
+            raise aefft.AefftError(f"aefft_dp_create failed with code {rc}")
+        self.h = h
+        self._err = aefft.AefftError
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._err(f"aefft_dp error {rc}: {self.L.aefft_dp_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aefft_dp_destroy(self.h)
+            self.h = None
+
+    def __call__(self, frames, recon, del0, maxdiff=0, sym=0, mse=None):
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.L.aefft_dp_step(self.h, p(frames), p(recon), del0, maxdiff, sym, p(mse)))
+
+    def run(self, frames, recon, del0, nsteps, maxdiff=0, sym=0):
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.L.aefft_dp_run(self.h, p(frames), p(recon), del0, maxdiff, sym, int(nsteps)))
+
+    def profile(self, frames, recon, del0, nsteps, maxdiff=0, sym=0):
+        """mean (grad half, all-reduce, update half) ms from events on the library's stream, and the host's microseconds per step"""
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        ph = (C.c_double * 3)(); host = C.c_double()
+        self._check(self.L.aefft_dp_profile(self.h, p(frames), p(recon), del0, maxdiff, sym, int(nsteps), ph, C.byref(host)))
+        return list(ph), host.value
+
+    def flush_mse(self):
+        import ctypes as C
+        out = np.zeros(self.net.npairs, np.float32)
+        self._check(self.L.aefft_dp_flush_mse(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def allreduce_bytes(self):
+        return int(self.L.aefft_dp_allreduce_bytes(self.h))
+
+    def replicas_agree(self):
+        r = self.L.aefft_dp_replicas_agree(self.h)
+        if r < 0:
+            raise self._err(f"aefft_dp_replicas_agree failed with code {r}")
+        return bool(r)

@@ -83,13 +83,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--preheat", type=int, default=300, help="untimed steps in front of the warm-up steps (clock ramp of the chip)")
+    ap.add_argument("--preheat", type=int, default=0, help="EXTRA untimed steps in front of the W warm-up steps (reported as preheat_steps; 0 = the contract's protocol)")
+    ap.add_argument("--steady-steps", type=int, default=200, help="steps of the second timed region behind the headline one (reported as steady_state; 0 = skip)")
+    ap.add_argument("--torch-dist-loop", action="store_true", help="N > 1: all-reduce through torch.distributed (dp.DataParallelStep) instead of libaefft_dp.so")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (weak scaling)")
     ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dp-probe", action="store_true", help="N = 1: skip the data_parallel block (a one-rank RCCL communicator, 20 untimed steps)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short extra runs (cfg3-P1, spatial mode) reported under \"variants\"")
     ap.add_argument("--flags", default="", help="comma-separated development switches (include/aefft.h AEFFT_F_*), e.g. NOOVERLAP,NOOPFORM")
     ap.add_argument("--rccl", action="store_true", help="initialise the nccl (RCCL) process group even at N = 1")
@@ -316,13 +319,26 @@ def main():
         # together with this step's reconstruction inverse FFT (tools/gap.py: a 40 us gap then costs +11 us per step instead of +32;
         # without a gap the mode costs +2 us, hence off at N = 1)
         net.set_input_ready(True)
-    dpstep = dp.DataParallelStep(net)                                     # step_grad -> RCCL all-reduce(SUM) -> step_apply(1/world)
     del0 = 0.2                                                            # autoencoder.cpp:87
+    # The step's host side.  N = 1: step_grad -> step_apply, nothing in between.  N > 1: libaefft_dp.so (include/aefft_dp.h) enqueues
+    # step_grad -> ncclAllReduce(SUM) on the library's stream -> step_apply(1/world) in ONE C call: no Python, no torch.distributed inside
+    # the step (torch.distributed only carries the ncclUniqueId, the barriers around the timed region and the max over ranks).
+    rstep = None
+    if world > 1 and not a.torch_dist_loop:
+        def bcast(idbuf):
+            t = idbuf.to(dev)
+            dist.broadcast(t, 0)
+            return t
+        rstep = dp.RcclStep(net, rank, world, bcast)
+    dpstep = dp.DataParallelStep(net)                                     # (--torch-dist-loop, and N = 1 where it is step_grad -> step_apply)
 
     def step():
         # (no per-step MSE output: the per-pair sums of a step are then formed by one more workgroup of the next step's gradient launch --
         # in time for the all-reduce that carries them -- instead of a launch of their own; net.last_mse() delivers them where they are read)
-        dpstep(frames, recon, del0, 0, 0, None)
+        if rstep is not None:
+            rstep(frames, recon, del0)
+        else:
+            dpstep(frames, recon, del0, 0, 0, None)
 
     def fence():
         ctx.sync()                      # the library's stream
@@ -331,9 +347,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Pre-heat: a FIXED amount of untimed work of the same kind in front of the W warm-up steps.  Measured (tools/steptimes.py): after
-    # idling through the set-up the chip takes ~10 ms of sustained load to reach its steady clocks -- the first 40 steps run 4-6 % slow --
-    # and a 20-step timed region (3.5 ms) would be measuring that ramp, not the step.
+    # The contract's protocol: W untimed warm-up steps, then exactly K timed steps between fences (--preheat adds EXTRA untimed steps in
+    # front and says so in the line: preheat_steps; default 0).  After idling through the set-up the chip takes ~10 ms of sustained load to
+    # reach its steady clocks (tools/steptimes.py: the first ~40 steps run 4-6 % slow), so a 20-step timed region reads that ramp; the
+    # SECOND timed region below (steady_state: --steady-steps more steps right behind the first) reads the step without it.
     mse_first = None
     for i in range(a.preheat + a.warmup):      # (the last a.warmup of them are the contract's W warm-up steps)
         step()
@@ -349,11 +366,49 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    steady = None
+    if a.steady_steps > 0:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steady_steps):
+            step()
+        fence()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        steady = {"steps": a.steady_steps, "ms_per_step": dts / a.steady_steps * 1e3, "frames_per_s": world * B * a.steady_steps / dts,
+                  "note": "second timed region, right behind the headline one (same fences, same step): the chip at its steady clocks"}
     net.last_mse(mse)
     ctx.sync()
     mse_host = mse.cpu().numpy().tolist()
     dp_diag = None
-    if dist is not None:
+    if rstep is not None or (world == 1 and not a.no_dp_probe and dist is None):
+        # Data-parallel diagnostics OUTSIDE the timed regions, through libaefft_dp.so: 20 more steps with events on the library's stream
+        # around the gradient half, the collective and the update half, and the HOST's time per step (enqueue only, no synchronisation).
+        # At N = 1 a communicator of one rank is created just for this: the all-reduce then runs through RCCL on the library's stream
+        # exactly as on 8 GPUs, and the line says what the collective's launch + the host path cost before the hardware shows up.
+        probe = rstep if rstep is not None else dp.RcclStep(net, 0, 1)
+        probe.run(frames, recon, del0, 3)
+        ph, host_us = probe.profile(frames, recon, del0, 20)
+        gm = probe.flush_mse().tolist()
+        agree = probe.replicas_agree()
+        allph = torch.tensor(ph + [host_us], dtype=torch.float64, device=dev)[None]
+        if world > 1:
+            g = [torch.zeros_like(allph) for _ in range(world)]
+            dist.all_gather(g, allph)
+            allph = torch.cat(g)
+        allph = allph.cpu().numpy()
+        mm = lambda c: {"min": float(allph[:, c].min()), "max": float(allph[:, c].max())}
+        dp_diag = {"steps": 20, "path": "libaefft_dp.so: step_grad -> ncclAllReduce on the library's stream -> step_apply in one C call per step",
+                   "grad_half_ms": mm(0), "allreduce_ms": mm(1), "apply_half_ms": mm(2), "host_us_per_step": mm(3),
+                   "host_budget_us_per_step": 100.0, "allreduce_bytes": probe.allreduce_bytes(), "replicas_agree": bool(agree),
+                   "global_batch_mse_per_pair": gm, "rccl_world": world,
+                   "note": "events on the library's stream; min / max over ranks; host_us = wall time the host spends enqueueing one step"}
+        if rstep is None:
+            probe.close()
+    elif dist is not None:
         # Data-parallel diagnostics, OUTSIDE the timed region (20 more steps with events on the library's stream around the two halves and
         # the collective): per-phase milliseconds as min / max over ranks, whether the replicas still hold identical weights, and the
         # global-batch MSE (the floats that ride in the gradient all-reduce)
@@ -401,6 +456,8 @@ def main():
         step_bytes = sum(v["bytes"] for v in prof.values()) / 3
         roof["step_algo_GB"] = step_bytes / 1e9
         roof["step_frac_of_hbm_peak"] = step_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS
+        if steady:
+            roof["step_frac_of_hbm_peak_steady_state"] = step_bytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     variants = None
     if rank == 0 and world == 1 and not a.no_variants and a.variant == "p2" and a.size == 512:
@@ -426,14 +483,20 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": world * B * a.steps / dt, "unit": "frames/s",
+            "metric": "frames/s fwd+bwd (FFT mode, 512x512, 4 layers)", "value": (world * B * a.steps / dt) if mse_finite else None, "unit": "frames/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup, "preheat_steps": a.preheat, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3-{a.variant.upper()}: {N}x{N}x3 frames, 4 pairs 3->8->16->32->64, 5x5, pool {s}/layer, FFT mode, "
-                                   f"fwd + 1 loop-body iteration per pair ({'per-frame form' if 'NOOPFORM' in a.flags else 'operator form'})", "frames_per_gpu": B, "global_batch": world * B,
+                                   f"fwd + 1 loop-body iteration per pair ({'per-frame form' if 'NOOPFORM' in a.flags else 'operator form'}); every step produces "
+                                   "reconstructions, batch-mean gradients, updated weights and the per-pair post-update MSE partial sums -- the sums themselves are "
+                                   "formed by the next step's gradient launch (no per-step MSE read-back inside the timed loop)", "frames_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of packed kernel-support gradients)" if world > 1 else "")},
             "mse_per_pair": mse_host, "mse_first_step": mse_first, "mse_finite": mse_finite,
         }
+        if not mse_finite:
+            out["invalid_reason"] = "non-finite post-update MSE at the end of the timed region: the measurement is void (value = null)"
+        if steady:
+            out["steady_state"] = steady
         if dp_diag:
             out["data_parallel"] = dp_diag
         if roof:

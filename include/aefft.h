@@ -176,6 +176,9 @@ typedef struct {
 
 int aefft_net_create(aefft_ctx* ctx, const aefft_net_desc* desc, aefft_net** out);
 void aefft_net_destroy(aefft_net* net);
+/* the descriptor back: number of pairs (negative for a null net); channels / maps / kernel support of pair l (any pointer nullable) */
+int aefft_net_npairs(aefft_net* net);
+int aefft_net_pair_shape(aefft_net* net, int l, int* dD, int* dM, int* Nk, int* Nl);
 /* weights of pair l (host pointers, reference layouts).  set = the caller's net_cfreq.clear():
  * spectra are rebuilt from c,f (fft_backproplib.cu:1148-1158). */
 int aefft_net_set_pair(aefft_net* net, int l, const float* c_h, const float* b_h, const float* f_h, const float* p_h);

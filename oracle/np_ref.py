@@ -289,13 +289,14 @@ def gradient_diff(c, f, b, p, dtype=np.float64):
     return cd, fd, bd, pd
 
 
-def gradient_diff_fast(c, f, b, p, block=64):
+def gradient_diff_fast(c, f, b, p, block=64, rows=None):
     """fft.cu:709-753 in float64, vectorised: the SAME sums as `gradient_diff` (which follows the source loop by loop) with the
     partner loop as array arithmetic, so that config 5's map counts (64 -> 128: 8192 kernels, 6.7e7 kernel pairs) run in seconds:
         g[i] = sum_{j: m_j != m_i and d_j != d_i} (K_i - K_j) / |K_i - K_j|^2  =  K_i * sum_j w_ij - sum_j w_ij K_j,
     w_ij = mask_ij / |K_i - K_j|^2 with the squared distances formed from the differences themselves (no |a|^2+|b|^2-2ab
     cancellation).  Checked against the literal loop nest in tests/test_oracle_fast.py.  Coinciding kernels give inf/nan as in
-    the source (`:724-746`).  Returns (cd, fd, bd, pd) like gradient_diff."""
+    the source (`:724-746`).  Returns (cd, fd, bd, pd) like gradient_diff.  `rows` (indices m*dD + d): only those kernels' sums are
+    formed -- cd[rows] and fd^T[rows] as [len(rows)][Nk][Nl] -- for spot checks of tensors too large to do whole."""
     c = np.asarray(c, np.float64); f = np.asarray(f, np.float64)
     b = np.asarray(b, np.float64); p = np.asarray(p, np.float64)
     dM, dD = c.shape[:2]
@@ -304,20 +305,23 @@ def gradient_diff_fast(c, f, b, p, block=64):
         n = dM * dD
         Kf = K.reshape(n, -1)
         mi = np.repeat(np.arange(dM), dD); di = np.tile(np.arange(dD), dM)
-        out = np.zeros_like(Kf)
+        sel = np.arange(n) if rows is None else np.asarray(rows)
+        out = np.zeros((len(sel), Kf.shape[1]))
         with np.errstate(divide="ignore", invalid="ignore"):
-            for i0 in range(0, n, block):
-                i1 = min(n, i0 + block)
-                diff = Kf[i0:i1, None, :] - Kf[None, :, :]                       # [bi][n][T]
+            for i0 in range(0, len(sel), block):
+                ii = sel[i0:i0 + block]
+                diff = Kf[ii, None, :] - Kf[None, :, :]                          # [bi][n][T]
                 dist = np.einsum("ijt,ijt->ij", diff, diff)
-                mask = (mi[i0:i1, None] != mi[None, :]) & (di[i0:i1, None] != di[None, :])
+                mask = (mi[ii, None] != mi[None, :]) & (di[ii, None] != di[None, :])
                 w = np.where(mask, 1.0 / np.where(mask, dist, 1.0), 0.0)
                 w = np.where(mask & (dist == 0.0), np.inf, w)
-                out[i0:i1] = Kf[i0:i1] * w.sum(axis=1)[:, None] - w @ Kf
-        return out.reshape(K.shape)
+                out[i0:i0 + len(ii)] = Kf[ii] * w.sum(axis=1)[:, None] - w @ Kf
+        return out.reshape(K.shape if rows is None else (len(sel),) + K.shape[2:])
 
     cd = one(c)
-    fd = np.transpose(one(np.transpose(f, (1, 0, 2, 3))), (1, 0, 2, 3)).copy()
+    fd = one(np.transpose(f, (1, 0, 2, 3)))
+    if rows is None:
+        fd = np.transpose(fd, (1, 0, 2, 3)).copy()
     with np.errstate(divide="ignore", invalid="ignore"):
         db_ = b[:, None] - b[None, :]; np.fill_diagonal(db_, np.inf)
         dp_ = p[:, None] - p[None, :]; np.fill_diagonal(dp_, np.inf)

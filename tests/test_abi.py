@@ -38,6 +38,22 @@ def test_python_prototypes_cover_header(built):
     assert sorted(aefft.SIGNATURES) == _declared()
 
 
+def test_data_parallel_library_exports_its_header():
+    """include/aefft_dp.h: libaefft_dp.so (libaefft.so + librccl) loads without a device and exports every declared symbol; the Python
+    prototype table covers them"""
+    if not os.path.exists(aefft.DP_LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "autoencoder-fft_amd", "csrc"), "dp"])
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aefft_dp.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(aefft_dp_[a-z0-9_]+)\s*\(", txt)))
+    assert len(names) == 10 and names == sorted(aefft.DP_SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", aefft.DP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert not [n for n in names if n not in exported]
+    aefft.dp_lib()
+    und = subprocess.run(["nm", "-D", "--undefined-only", aefft.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "nccl" not in und, "libaefft.so itself must not depend on RCCL"
+
+
 def test_flag_table_matches_header():
     txt = open(os.path.join(ROOT, "include", "aefft.h")).read()
     hdr = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"AEFFT_F_([A-Z]+)\s*=\s*1\s*<<\s*(\d+)", txt)}

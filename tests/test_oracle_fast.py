@@ -21,6 +21,10 @@ def test_gradient_diff_fast_equals_the_literal_loop_nest(dM, dD, Nk, Nl, block):
     for a, g in zip(lit, fast):
         assert a.shape == g.shape
         assert np.abs(a - g).max() <= 1e-13 * max(1.0, np.abs(a).max())
+    rows = [0, dM * dD - 1, (dM * dD) // 2]
+    part = R.gradient_diff_fast(c, f, b, p, rows=rows)
+    assert np.array_equal(part[0], fast[0].reshape(dM * dD, Nk, Nl)[rows])
+    assert np.array_equal(part[1], np.transpose(fast[1], (1, 0, 2, 3)).reshape(dM * dD, Nk, Nl)[rows])
     if dD == 1:       # fft.cu:724 needs d1 != d AND m1 != m: a single input channel has no partner (SURVEY B-9)
         assert not lit[0].any() and not fast[0].any()
 
