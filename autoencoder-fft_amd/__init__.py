@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaefft.so")
+# (AEFFT_LIB: development only -- tools/x*.sh point the binding at an experiment build under build_x/ instead of copying it over the product)
+LIB_PATH = os.environ.get("AEFFT_LIB") or os.path.join(_HERE, "libaefft.so")
 
 OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 

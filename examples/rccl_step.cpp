@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <unistd.h>
 #include <vector>
 
 #define CK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s failed: %d (%s)\n", #x, r_, ctx ? aefft_last_error(ctx) : ""); return 1; } } while (0)
@@ -36,12 +38,23 @@ int main()
     const char* idf = getenv("AEFFT_NCCL_ID_FILE");
     if (rank == 0) {
         NK(ncclGetUniqueId(&id));
-        if (world > 1) { if (!idf) { fprintf(stderr, "AEFFT_NCCL_ID_FILE not set\n"); return 1; } FILE* f = fopen(idf, "wb"); fwrite(&id, sizeof id, 1, f); fclose(f); }
+        if (world > 1) {
+            // written under a temporary name and renamed into place: a reader never sees a partial file.  The launcher removes a stale
+            // file of an earlier run before it starts the ranks (tests/test_gpu_round4.py does).
+            if (!idf) { fprintf(stderr, "AEFFT_NCCL_ID_FILE not set\n"); return 1; }
+            const std::string tmp = std::string(idf) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof id, 1, f) != 1 || fclose(f) != 0 || rename(tmp.c_str(), idf) != 0) { fprintf(stderr, "cannot write the nccl id to %s\n", idf); return 1; }
+        }
     } else {
-        FILE* f = nullptr;
-        for (int t = 0; t < 600 && !(f = fopen(idf ? idf : "", "rb")); ++t) (void)hipDeviceSynchronize();
-        if (!f || fread(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot read the nccl id\n"); return 1; }
-        fclose(f);
+        if (!idf) { fprintf(stderr, "AEFFT_NCCL_ID_FILE not set\n"); return 1; }
+        bool got = false;
+        for (int t = 0; t < 600 && !got; ++t) {                       // up to 60 s
+            FILE* f = fopen(idf, "rb");
+            if (f) { got = fread(&id, sizeof id, 1, f) == 1; fclose(f); }
+            if (!got) usleep(100 * 1000);
+        }
+        if (!got) { fprintf(stderr, "cannot read the nccl id from %s\n", idf); return 1; }
     }
     ncclComm_t comm;
     NK(ncclCommInitRank(&comm, world, id, rank));

@@ -1,10 +1,9 @@
 #!/bin/bash
-# dev tool (GPU box): plain bench (no profiler) of experiment builds build_x/libaefft_x*.so swapped in for libaefft.so
+# dev tool (GPU box): plain bench (no profiler) of experiment builds build_x/libaefft_x*.so against the product library (AEFFT_LIB selects
+# the build; the product's libaefft.so is never overwritten)
 R=$(cd "$(dirname "$0")/.." && pwd)
-cp $R/autoencoder-fft_amd/libaefft.so /tmp/libaefft_base.so
-for f in /tmp/libaefft_base.so $R/build_x/libaefft_x*.so; do
-  cp $f $R/autoencoder-fft_amd/libaefft.so
+for f in $R/autoencoder-fft_amd/libaefft.so $R/build_x/libaefft_x*.so; do
+  export AEFFT_LIB=$f
   echo "== $(basename $f .so)"
-  for i in 1 2; do python $R/bench.py --steps 200 --no-cpu-baseline --no-roofline --no-variants "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
+  for i in 1 2; do python $R/bench.py --steps 200 --steady-steps 0 --no-dp-probe --no-cpu-baseline --no-roofline --no-variants "$@" 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
 done
-cp /tmp/libaefft_base.so $R/autoencoder-fft_amd/libaefft.so
