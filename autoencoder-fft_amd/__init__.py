@@ -45,6 +45,7 @@ SIGNATURES = {
     "aefft_ctx_destroy": (None, [_vp]),
     "aefft_last_error": (C.c_char_p, [_vp]),
     "aefft_sync": (_i, [_vp]),
+    "aefft_ctx_partition": (_i, [_vp, _i]),
     "aefft_ctx_set_flags": (_i, [_vp, C.c_uint]),
     "aefft_ctx_get_flags": (C.c_uint, [_vp]),
     "aefft_stream": (_vp, [_vp]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "aefft_pool_spatial": (_i, [_vp, _fp, _fp, C.c_long, _i, _i, _i, _i, _i]),
     "aefft_pool_conv_spatial": (_i, [_vp, _fp, _fp, _fp, _fp, _fp] + [_i] * 9),
     "aefft_backprop_spatial": (_i, [_vp] + [_fp] * 15 + [_i] * 7 + [_f, _f, _i, _i]),
+    "aefft_step_spatial": (_i, [_vp] + [_fp] * 15 + [_i] * 7 + [_f, _f, _i, _i]),
     "aefft_net_create": (_i, [_vp, C.POINTER(NetDesc), C.POINTER(_vp)]),
     "aefft_net_destroy": (None, [_vp]),
     "aefft_net_npairs": (_i, [_vp]),
@@ -200,6 +202,10 @@ class Context:
 
     def sync(self):
         self.check(self.L.aefft_sync(self.h))
+
+    def partition(self, side_cus):
+        """aefft_ctx_partition: CU-masked streams -- the side streams get `side_cus` compute units, the context stream the rest"""
+        self.check(self.L.aefft_ctx_partition(self.h, int(side_cus)))
 
     def torch_stream(self):
         """The library's stream as a torch stream object (so collectives / torch ops can be ordered on it)."""
@@ -350,6 +356,19 @@ class Context:
                                                  _ptr(dc), _ptr(db), _ptr(df), _ptr(dp), _ptr(ddc), _ptr(ddb), _ptr(ddf), _ptr(ddp),
                                                  B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, 1 if tied else 0,
                                                  {"gpu": 0, "cpu": 1, "cuda_compat": 2}[semantics]))
+
+    def step_spatial(self, x, c, b, f, p, mom, grads, delmax, alpha, tied=False, semantics="gpu", hin=None, out=None):
+        """Conv_gpu + Conv_gpu + backprop_gpu[_cc] in one call (aefft_step_spatial); returns (hin, out)."""
+        B, dD, Nx, Ny = x.shape
+        dM, _, Nk, Nl = c.shape
+        hin = self.empty(B, dM, Nx, Ny) if hin is None else hin
+        out = self.empty(B, dD, Nx, Ny) if out is None else out
+        dc, db, df, dp = mom
+        ddc, ddb, ddf, ddp = grads
+        self.check(self.L.aefft_step_spatial(self.h, _ptr(x), _ptr(hin), _ptr(out), _ptr(c), _ptr(b), _ptr(f), _ptr(p),
+                                             _ptr(dc), _ptr(db), _ptr(df), _ptr(dp), _ptr(ddc), _ptr(ddb), _ptr(ddf), _ptr(ddp),
+                                             B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, 1 if tied else 0, {"gpu": 0, "cpu": 1}[semantics]))
+        return hin, out
 
     def set_flags(self, *names):
         """Development switches (include/aefft.h AEFFT_F_*), by name without the prefix; no names = defaults."""

@@ -3,6 +3,7 @@
 #include "../../include/aefft.h"
 #include "internal.h"
 
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ struct aefft_ctx {
     static const int NAUX = 2;
     hipStream_t aux[NAUX] = {};      // side streams: 0 = reconstruction inverse FFT, 1 = input prefetch (created with the first net)
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {};
+    int side_cus = 0;                // aefft_ctx_partition: CUs of the side streams (0: no partition)
     std::string err;
     const float2* tw = nullptr;      // device twiddle table
     void* ws[WS_COUNT] = {};
@@ -179,6 +181,21 @@ extern "C" void aefft_ctx_destroy(aefft_ctx* ctx)
     delete ctx;
 }
 
+// CU mask of one side of the partition: the side streams take mask bits [0, side_cus), the context stream the rest.  (Mask bits are dealt
+// to the XCDs round-robin by the driver -- tools/cumask_probe.hip -- so a run of consecutive bits is the same share of every XCD.)
+static hipError_t masked_stream(hipStream_t* st, int ncu, int lo, int hi)
+{
+    std::vector<uint32_t> m((size_t)(ncu + 31) / 32, 0u);
+    for (int i = lo; i < hi; ++i) m[(size_t)i / 32] |= 1u << (i % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)m.size(), m.data());
+}
+static int device_cus(int device)
+{
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return n;
+}
+
 // side streams (0: reconstruction inverse FFT, 1: input prefetch) and their events; all-or-nothing
 static int ensure_aux(aefft_ctx* ctx)
 {
@@ -187,6 +204,8 @@ static int ensure_aux(aefft_ctx* ctx)
     for (int i = 0; i < aefft_ctx::NAUX && e == hipSuccess; ++i) {
         int pr_least = 0, pr_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        if (ctx->side_cus > 0) e = masked_stream(&ctx->aux[i], device_cus(ctx->device), 0, ctx->side_cus);
+        else
         e = hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, pr_least);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
     }
@@ -200,6 +219,26 @@ static int ensure_aux(aefft_ctx* ctx)
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->ev_fork = nullptr;
     return fail(ctx, AEFFT_EHIP, "side streams", e);
+}
+
+extern "C" int aefft_ctx_partition(aefft_ctx* ctx, int side_cus)
+{
+    if (!ctx) return AEFFT_EINVAL;
+    if (!ctx->own_stream || ctx->aux[0]) return fail(ctx, AEFFT_ESTATE, "aefft_ctx_partition: needs a context that owns its stream, before its first net");
+    const int ncu = device_cus(ctx->device);
+    if (side_cus < 0 || (side_cus > 0 && (ncu < 16 || side_cus < 8 || side_cus > ncu - 8))) return fail(ctx, AEFFT_EINVAL, "aefft_ctx_partition: side_cus out of range");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st = nullptr;
+    if (side_cus > 0) HIPCHK(ctx, masked_stream(&st, ncu, side_cus, ncu));
+    else {
+        int pr_least = 0, pr_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr_greatest));
+    }
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = ctx->cur = st;
+    ctx->side_cus = side_cus;
+    return AEFFT_OK;
 }
 
 extern "C" const char* aefft_last_error(const aefft_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -272,9 +311,56 @@ static int chk_size(aefft_ctx* ctx, int Nx, int Ny)
     return AEFFT_OK;
 }
 
+static int chk_size_any(aefft_ctx* ctx, int Nx, int Ny)
+{
+    if ((fft_size_supported(Nx) && fft_size_supported(Ny)) || (fft_size_supported_any(Nx) && fft_size_supported_any(Ny) && Nx <= 1024 && Ny <= 1024)) return AEFFT_OK;
+    return fail(ctx, AEFFT_EINVAL, "Nx, Ny must be powers of two in 8..2048, or even sizes in 8..1024");
+}
+static bool pow2_sizes(int Nx, int Ny) { return fft_size_supported(Nx) && fft_size_supported(Ny); }
+static int do_resize(aefft_ctx* ctx, const float2* in, float2* out, long planes, int Nx, int Ny, int Nxs, int Nys);
+
+// sizes that are not powers of two (fft_backproplib.cu:773-779: cufftPlanMany takes any): Bluestein rows + transposes (fft_kernels.hip);
+// the spectral crop / zero-pad as a separate resize
+static int do_r2c_any(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys)
+{
+    const size_t el = fft_any_ws_elems(planes, Nx, Ny);
+    void *w1, *w2, *w3 = nullptr;
+    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * el, &w1));
+    RET_IF(ws_get(ctx, WS_MID2, sizeof(float2) * el, &w2));
+    const bool crop = Nxs != Nx || Nys != Ny;
+    if (crop) RET_IF(ws_get(ctx, WS_MID3, sizeof(float2) * el, &w3));
+    {
+        Bracket br(ctx, KID_R2C_ROWS, (double)planes * ((double)Nx * Ny * 4.0 + (double)bins(Nx, Ny) * 8.0));
+        hipError_t e = launch_r2c_any(x, crop ? (float2*)w3 : X, (float2*)w1, (float2*)w2, planes, Nx, Ny, ctx->cur);
+        if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c (any size)", e);
+    }
+    return crop ? do_resize(ctx, (const float2*)w3, X, planes, Nx, Ny, Nxs, Nys) : AEFFT_OK;
+}
+static int do_c2r_any(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale)
+{
+    const size_t el = fft_any_ws_elems(planes, Nx, Ny);
+    void *w1, *w2, *w3 = nullptr;
+    RET_IF(ws_get(ctx, WS_MID, sizeof(float2) * el, &w1));
+    RET_IF(ws_get(ctx, WS_MID2, sizeof(float2) * el, &w2));
+    const bool pad = Nxi != Nx || Nyi != Ny;
+    if (pad) {
+        RET_IF(ws_get(ctx, WS_MID3, sizeof(float2) * el, &w3));
+        RET_IF(do_resize(ctx, X, (float2*)w3, planes, Nxi, Nyi, Nx, Ny));
+    }
+    Bracket br(ctx, KID_C2R_ROWS, (double)planes * ((double)Nx * Ny * 4.0 + (double)bins(Nx, Ny) * 8.0));
+    hipError_t e = launch_c2r_any(pad ? (const float2*)w3 : X, x, (float2*)w1, (float2*)w2, planes, Nx, Ny, scale, ctx->cur);
+    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "c2r (any size)", e);
+    return AEFFT_OK;
+}
+
 // R2C (+ fused crop to Nxs x Nys).  The two kernels are bracketed separately for profiling.
 static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys, int ws_id = WS_MID, hipEvent_t done = nullptr)
 {
+    if (!pow2_sizes(Nx, Ny) || !pow2_sizes(Nxs, Nys)) {
+        RET_IF(chk_size_any(ctx, Nx, Ny));
+        if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
+        return do_r2c_any(ctx, x, X, planes, Nx, Ny, Nxs, Nys);
+    }
     RET_IF(chk_size(ctx, Nx, Ny));
     if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
     void* mid;
@@ -300,6 +386,11 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
 static int do_c2r(aefft_ctx* ctx, const float2* X, float* x, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, int ws_id = WS_MID,
                   const OpIn* opin = nullptr)
 {
+    if (!opin && (!pow2_sizes(Nx, Ny) || !pow2_sizes(Nxi, Nyi))) {
+        RET_IF(chk_size_any(ctx, Nx, Ny));
+        if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
+        return do_c2r_any(ctx, X, x, planes, Nxi, Nyi, Nx, Ny, scale);
+    }
     RET_IF(chk_size(ctx, Nx, Ny));
     if (!aligned16(x) || (!opin && !aligned16(X))) return fail(ctx, AEFFT_EINVAL, "c2r: pointers must be 16-byte aligned");
     void* mid;
@@ -683,11 +774,15 @@ extern "C" int aefft_c2r(aefft_ctx* ctx, const float* X_d, float* x_d, long plan
     return do_c2r(ctx, CF2(X_d), x_d, planes, Nx, Ny, Nx, Ny, scale);
 }
 
+// op level: any integer scale, sized as the reference sizes it (fft_backproplib.cu:980-984: l = scale or 1/|scale| as FLOAT, Nxs = int(Nx / l) --
+// exact for powers of two, SURVEY B-4, and for the other scales whatever that float arithmetic gives); the resized grid must be even (the
+// index rules of `resize`, :98-153, are written for even sizes) and a size the transforms serve
 static int chk_scale(aefft_ctx* ctx, int Nx, int Ny, int scale, int* Nxs, int* Nys)
 {
-    const int a = scale < 0 ? -scale : scale;
-    if (scale == 0 || !pow2(a)) return fail(ctx, AEFFT_EINVAL, "pooling scale must be a non-zero power of two (SURVEY B-4)");
-    pooled(Nx, Ny, scale, Nxs, Nys);
+    if (scale == 0) return fail(ctx, AEFFT_EINVAL, "pooling scale must be non-zero");
+    const float l = scale > 0 ? (float)scale : -1.0f / (float)scale;
+    *Nxs = (int)((float)Nx / l); *Nys = (int)((float)Ny / l);
+    if ((*Nxs & 1) || (*Nys & 1)) return fail(ctx, AEFFT_EINVAL, "pooled size must be even");
     if (*Nxs < 8 || *Nys < 8 || *Nxs > 2048 || *Nys > 2048) return fail(ctx, AEFFT_EINVAL, "pooled size out of range 8..2048");
     return AEFFT_OK;
 }
@@ -695,7 +790,7 @@ static int chk_scale(aefft_ctx* ctx, int Nx, int Ny, int scale, int* Nxs, int* N
 extern "C" int aefft_pool(aefft_ctx* ctx, const float* X_d, float* Xs_d, long planes, int Nx, int Ny, int scale, int* Nxs, int* Nys)
 {
     if (!ctx || !X_d || !Xs_d || planes < 0) return fail(ctx, AEFFT_EINVAL, "aefft_pool: bad argument");
-    RET_IF(chk_size(ctx, Nx, Ny));
+    RET_IF(chk_size_any(ctx, Nx, Ny));
     int nx, ny;
     RET_IF(chk_scale(ctx, Nx, Ny, scale, &nx, &ny));
     if (Nxs) *Nxs = nx;
@@ -840,12 +935,44 @@ extern "C" int aefft_pool_spatial(aefft_ctx* ctx, const float* in_d, float* out_
     return AEFFT_OK;
 }
 
+static int backprop_spatial_impl(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
+                                 float* c_d, float* b_d, float* f_d, float* p_d,
+                                 float* dc_d, float* db_d, float* df_d, float* dp_d,
+                                 float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                                 int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                                 float delmax, float alpha, int tied, int cpu_semantics, bool hin_is_conv);
+
 extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
                                       float* c_d, float* b_d, float* f_d, float* p_d,
                                       float* dc_d, float* db_d, float* df_d, float* dp_d,
                                       float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
                                       int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
                                       float delmax, float alpha, int tied, int cpu_semantics)
+{
+    return backprop_spatial_impl(ctx, in_d, out_d, hin_d, c_d, b_d, f_d, p_d, dc_d, db_d, df_d, dp_d, ddc_d, ddb_d, ddf_d, ddp_d,
+                                 B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, tied, cpu_semantics, false);
+}
+
+extern "C" int aefft_step_spatial(aefft_ctx* ctx, const float* in_d, float* hin_d, float* out_d,
+                                  float* c_d, float* b_d, float* f_d, float* p_d,
+                                  float* dc_d, float* db_d, float* df_d, float* dp_d,
+                                  float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                                  int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                                  float delmax, float alpha, int tied, int cpu_semantics)
+{
+    if (!ctx || !in_d || !out_d || !hin_d || cpu_semantics < 0 || cpu_semantics > 1) return fail(ctx, AEFFT_EINVAL, "aefft_step_spatial: bad argument");
+    RET_IF(aefft_conv_spatial(ctx, in_d, hin_d, c_d, b_d, B, dD, dM, Nx, Ny, Nk, Nl, cpu_semantics));
+    RET_IF(aefft_conv_spatial(ctx, hin_d, out_d, f_d, p_d, B, dM, dD, Nx, Ny, Nk, Nl, cpu_semantics));
+    return backprop_spatial_impl(ctx, in_d, out_d, hin_d, c_d, b_d, f_d, p_d, dc_d, db_d, df_d, dp_d, ddc_d, ddb_d, ddf_d, ddp_d,
+                                 B, dD, dM, Nx, Ny, Nk, Nl, delmax, alpha, tied, cpu_semantics, true);
+}
+
+static int backprop_spatial_impl(aefft_ctx* ctx, const float* in_d, const float* out_d, const float* hin_d,
+                                 float* c_d, float* b_d, float* f_d, float* p_d,
+                                 float* dc_d, float* db_d, float* df_d, float* dp_d,
+                                 float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                                 int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                                 float delmax, float alpha, int tied, int cpu_semantics, bool hin_is_conv)
 {
     if (!ctx || !in_d || !out_d || !hin_d || !c_d || !b_d || !f_d || !p_d || !dc_d || !db_d || !df_d || !dp_d || B <= 0)
         return fail(ctx, AEFFT_EINVAL, "aefft_backprop_spatial: bad argument");
@@ -870,8 +997,13 @@ extern "C" int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const f
     a.Norm = (float)(dD * dM * Nk * Nl * Nx * Ny);            // backproplib.cu:303
     if (tied) a.Norm = (float)(2 * dD * dM * Nk * Nl * Nx * Ny);   // :533
     a.tied = tied;
+    if (hin_is_conv && spatial_regions_ok(a)) {
+        // the hidden layer is this call's own Conv_gpu(in; c, b): dF and dP come out of the error-input region sums as dC and dB do, the
+        // hidden layer is not read again (the weights are read before the update below changes them: stream order)
+        a.c1 = c_d; a.b1 = b_d; a.div1 = cpu_semantics == 1 ? 1.f : (float)dM;
+    }
     {
-        Bracket br(ctx, KID_SPATIAL, (double)B * (3.0 * dD + 2.0 * dM) * Nx * Ny * 4.0);
+        Bracket br(ctx, KID_SPATIAL, (double)B * ((a.c1 ? 2.0 : 3.0) * dD + (a.c1 ? 0.0 : 1.0) * dM) * Nx * Ny * 4.0);
         hipError_t e = launch_spatial_grad(a, ctx->stream);
         if (e == hipSuccess && cpu_semantics == 2) e = launch_spatial_compat(a, ctx->stream);      // Appendix B-11: bug-compatible gf, gb
         if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "spatial_grad", e);

@@ -13,6 +13,8 @@ typedef float nt_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ld_stream(const float4* p) { const nt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float2 ld_stream(const float2* p) { const nt_v2f v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2f*>(p)); return make_float2(v.x, v.y); }
 __device__ __forceinline__ void st_stream(float4* p, float4 a) { const nt_v4f v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<nt_v4f*>(p)); }
+__device__ __forceinline__ void st_stream(float2* p, float2 a) { const nt_v2f v = {a.x, a.y}; __builtin_nontemporal_store(v, reinterpret_cast<nt_v2f*>(p)); }
+__device__ __forceinline__ void st_stream(float* p, float a) { __builtin_nontemporal_store(a, p); }
 
 // destination bin of source bin (i, j) under the spectral crop [Nx][Ny/2+1] -> [Nxs][Nys/2+1] (inverse of fft.cu:102-111), or -1
 __device__ __forceinline__ long crop_dest(long bin, int Nx, int Ny, int Nxs, int Nys)

@@ -24,6 +24,7 @@
 #include "device_util.h"
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <map>
 #include <vector>
 
 namespace aefft {
@@ -293,10 +294,9 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     extern __shared__ float2 s[];
     const int tid = threadIdx.x;
     const int g = tid / T, t = tid % T;
-    const long pair0 = (long)blockIdx.x * G;
     FftTw<N, +1> tws;
     tws.load(t);
-
+    const long pair0 = (long)blockIdx.x * G;
     // Z[k] = A[k] + i*B[k], Z[N-k] = conj(A[k]) + i*conj(B[k]); k handled in pairs (k, k+1), k even < N/2
     constexpr int NIT = G * (N / 4) / NT;                       // = 2 when NT = G*N/8
     static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of items per thread");
@@ -509,6 +509,109 @@ __global__ __launch_bounds__(CW* N / 8) void inv_cols_kernel(const float2* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// sizes that are not powers of two
+// ------------------------------------------------------------------------------------------
+// The reference hands any {Nx, Ny} to cufftPlanMany (fft_backproplib.cu:773-779, 885, 1208) and any integer Pooling_scale to pool_fft
+// (:980-984).  Here an n-point DFT with n not a power of two is re-expressed by Bluestein's identity  j k = (j^2 + k^2 - (k - j)^2) / 2  as a
+// circular convolution of length M = 2^q >= 2n - 1 with the chirp w[j] = exp(DIR i pi j^2 / n):
+//     X[k] = w[k] * sum_j (x[j] w[j]) conj(w)[k - j]
+// and runs on the power-of-two LDS Stockham passes above (forward transform of length M, product with the chirp's spectrum, inverse
+// transform).  One kernel transforms ROWS (contiguous); the 2-D transforms go rows -> transpose -> rows -> transpose.  Even n in 8..1024.
+// MODE 0: complex rows -> complex rows;  1: real rows -> half spectra (n/2+1);  2: half spectra -> real rows (Hermitian extension on load,
+// imaginary parts of the self-conjugate bins ignored -- pocketfft / numpy.irfft semantics, as the power-of-two path).
+__device__ __forceinline__ float2 chirp(int j, int n, int dir)
+{
+    // exp(dir * i * pi * j^2 / n), the phase reduced exactly in integers: j^2 mod 2n
+    const unsigned q = ((unsigned)j * (unsigned)j) % (2u * (unsigned)n);
+    float sn, cs;
+    sincospif((float)q / (float)n, &sn, &cs);
+    return make_float2(cs, dir < 0 ? -sn : sn);
+}
+
+template <int M> struct BluCfg {
+    static constexpr int T = M / 8;
+    static constexpr int NT = T > 256 ? T : 256;
+    static constexpr int G = NT / T;
+    static constexpr int PL = pad_len(M);
+};
+
+// spectrum of the chirp filter b[j] = conj(w[j]) (|j| < n, wrapped into M points), once per (n, M, DIR): bhat[M]
+template <int M>
+__global__ __launch_bounds__(BluCfg<M>::T) void bluestein_setup_kernel(float2* __restrict__ bhat, int n, int dir)
+{
+    constexpr int T = BluCfg<M>::T;
+    extern __shared__ float2 s[];
+    const int t = threadIdx.x;
+    FftTw<M, -1> tws;
+    tws.load(t);
+    for (int j = t; j < M; j += T) {
+        const int jj = j < n ? j : (M - j < n ? M - j : -1);
+        float2 v = make_float2(0.f, 0.f);
+        if (jj >= 0) { v = chirp(jj, n, dir); v.y = -v.y; }
+        s[pad_idx(j)] = v;
+    }
+    __syncthreads();
+    fft_lds<M, -1>(s, t, tws);
+    for (int j = t; j < M; j += T) bhat[j] = s[pad_idx(j)];
+}
+
+template <int M, int MODE>
+__global__ __launch_bounds__(BluCfg<M>::NT) void bluestein_rows_kernel(const void* __restrict__ in_, void* __restrict__ out_, const float2* __restrict__ bhat,
+                                                                        long nrows, int n, int dir, float scale)
+{
+    using Cfg = BluCfg<M>;
+    constexpr int T = Cfg::T, NT = Cfg::NT, G = Cfg::G, PL = Cfg::PL;
+    extern __shared__ float2 s[];
+    const int tid = threadIdx.x, g = tid / T, t = tid % T;
+    const long row = (long)blockIdx.x * G + g;
+    const bool live = row < nrows;
+    FftTw<M, -1> twf;
+    FftTw<M, +1> twi;
+    twf.load(t); twi.load(t);
+    float2* z = s + g * PL;
+    const int nh = n / 2 + 1;
+    for (int j = t; j < M; j += T) {
+        float2 v = make_float2(0.f, 0.f);
+        if (live && j < n) {
+            if (MODE == 0) v = reinterpret_cast<const float2*>(in_)[row * n + j];
+            else if (MODE == 1) v = make_float2(reinterpret_cast<const float*>(in_)[row * n + j], 0.f);
+            else {
+                const float2* X = reinterpret_cast<const float2*>(in_) + row * nh;
+                if (j < nh) { v = X[j]; if (j == 0 || 2 * j == n) v.y = 0.f; }
+                else { v = X[n - j]; v.y = -v.y; }
+            }
+            v = cmul(v, chirp(j, n, dir));
+        }
+        z[pad_idx(j)] = v;
+    }
+    __syncthreads();
+    fft_lds<M, -1>(z, t, twf);
+    for (int j = t; j < M; j += T) z[pad_idx(j)] = cmul(z[pad_idx(j)], bhat[j]);
+    __syncthreads();
+    fft_lds<M, +1>(z, t, twi);
+    if (!live) return;
+    const float sc = scale / (float)M;
+    const int nout = MODE == 1 ? nh : n;
+    for (int k = t; k < nout; k += T) {
+        float2 v = cmul(z[pad_idx(k)], chirp(k, n, dir));
+        if (MODE == 2) reinterpret_cast<float*>(out_)[row * n + k] = v.x * sc;
+        else reinterpret_cast<float2*>(out_)[row * nout + k] = make_float2(v.x * sc, v.y * sc);
+    }
+}
+
+// [planes][R][C] -> [planes][C][R]
+__global__ __launch_bounds__(256) void transpose_c_kernel(const float2* __restrict__ in, float2* __restrict__ out, int R, int C)
+{
+    __shared__ float2 tile[32][33];
+    const long plane = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    for (int k = ty; k < 32; k += 8) if (r0 + k < R && c0 + tx < C) tile[k][tx] = in[(plane * R + r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) if (c0 + k < C && r0 + tx < R) out[(plane * C + c0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 size_t fft_mid_elems(long planes, int Nx, int Wc) { return (size_t)planes * Nx * Wc; }
@@ -590,6 +693,104 @@ template <int N, bool FWD> static hipError_t cols_dispatch(const float2* a, floa
     case 2048: { constexpr int NN = 2048; CALL; }     \
     default: e = hipErrorInvalidValue;                \
     }
+
+// ---- any even size in 8..1024 (Bluestein) ----
+bool fft_size_supported_any(int n) { return fft_size_supported(n) || (n >= 8 && n <= 1024 && (n & 1) == 0); }
+static int blu_m(int n) { int m = 16; while (m < 2 * n - 1) m *= 2; return m; }
+// the chirp spectra, once per (device, n, DIR); they live for the life of the process (a few KB each)
+struct BluKey { int dev, n, dir; bool operator<(const BluKey& o) const { return dev != o.dev ? dev < o.dev : (n != o.n ? n < o.n : dir < o.dir); } };
+#define AEFFT_M_SWITCH(m, CALL)                      \
+    switch (m) {                                      \
+    case 16: { constexpr int MM = 16; CALL; }         \
+    case 32: { constexpr int MM = 32; CALL; }         \
+    case 64: { constexpr int MM = 64; CALL; }         \
+    case 128: { constexpr int MM = 128; CALL; }       \
+    case 256: { constexpr int MM = 256; CALL; }       \
+    case 512: { constexpr int MM = 512; CALL; }       \
+    case 1024: { constexpr int MM = 1024; CALL; }     \
+    case 2048: { constexpr int MM = 2048; CALL; }     \
+    default: e = hipErrorInvalidValue;                \
+    }
+template <int M> static hipError_t run_blu_setup(float2* bhat, int n, int dir, hipStream_t st)
+{
+    bluestein_setup_kernel<M><<<1, BluCfg<M>::T, sizeof(float2) * pad_len(M), st>>>(bhat, n, dir);
+    return hipGetLastError();
+}
+static hipError_t blu_table(int n, int dir, hipStream_t st, const float2** out)
+{
+    static std::map<BluKey, float2*> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const BluKey key{dev, n, dir};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        const int M = blu_m(n);
+        float2* p = nullptr;
+        e = hipMalloc(&p, sizeof(float2) * M);
+        if (e != hipSuccess) return e;
+        AEFFT_M_SWITCH(M, e = run_blu_setup<MM>(p, n, dir, st); break)
+        if (e == hipSuccess) e = hipStreamSynchronize(st);      // (once per size: the table must be complete before another stream uses it)
+        if (e != hipSuccess) { (void)hipFree(p); return e; }
+        it = cache.emplace(key, p).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
+template <int M, int MODE> static hipError_t run_blu_rows(const void* in, void* out, const float2* bhat, long nrows, int n, int dir, float scale, hipStream_t st)
+{
+    using Cfg = BluCfg<M>;
+    const size_t lds = sizeof(float2) * (size_t)Cfg::G * Cfg::PL;
+    hipError_t e = allow_lds(bluestein_rows_kernel<M, MODE>, lds);
+    if (e != hipSuccess) return e;
+    const long blocks = (nrows + Cfg::G - 1) / Cfg::G;
+    if (blocks >= (1L << 31)) return hipErrorInvalidValue;
+    bluestein_rows_kernel<M, MODE><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(in, out, bhat, nrows, n, dir, scale);
+    return hipGetLastError();
+}
+static hipError_t blu_rows(int mode, const void* in, void* out, long nrows, int n, int dir, float scale, hipStream_t st)
+{
+    const float2* bhat = nullptr;
+    hipError_t e = blu_table(n, dir, st, &bhat);
+    if (e != hipSuccess) return e;
+    const int M = blu_m(n);
+    if (mode == 0) { AEFFT_M_SWITCH(M, e = (run_blu_rows<MM, 0>(in, out, bhat, nrows, n, dir, scale, st)); break) }
+    else if (mode == 1) { AEFFT_M_SWITCH(M, e = (run_blu_rows<MM, 1>(in, out, bhat, nrows, n, dir, scale, st)); break) }
+    else { AEFFT_M_SWITCH(M, e = (run_blu_rows<MM, 2>(in, out, bhat, nrows, n, dir, scale, st)); break) }
+    return e;
+}
+static hipError_t transpose_c(const float2* in, float2* out, long planes, int R, int C, hipStream_t st)
+{
+    if (planes > 65535) return hipErrorInvalidValue;
+    transpose_c_kernel<<<dim3((C + 31) / 32, (R + 31) / 32, (unsigned)planes), 256, 0, st>>>(in, out, R, C);
+    return hipGetLastError();
+}
+// complex elements each of the two workspaces of the any-size transforms needs
+size_t fft_any_ws_elems(long planes, int Nx, int Ny) { return (size_t)planes * Nx * (Ny / 2 + 1); }
+// unnormalised 2-D R2C of any even size: in [planes][Nx][Ny] -> out [planes][Nx][Ny/2+1]; w1, w2: fft_any_ws_elems complex each
+hipError_t launch_r2c_any(const float* in, float2* out, float2* w1, float2* w2, long planes, int Nx, int Ny, hipStream_t st)
+{
+    if (!fft_size_supported_any(Nx) || !fft_size_supported_any(Ny) || Nx > 1024 || Ny > 1024) return hipErrorInvalidValue;
+    if (planes <= 0) return hipSuccess;
+    const int Nyr = Ny / 2 + 1;
+    hipError_t e = blu_rows(1, in, w1, planes * Nx, Ny, -1, 1.f, st);                     // rows: real -> half spectra  [planes][Nx][Nyr]
+    if (e == hipSuccess) e = transpose_c(w1, w2, planes, Nx, Nyr, st);                     //                             [planes][Nyr][Nx]
+    if (e == hipSuccess) e = blu_rows(0, w2, w1, planes * Nyr, Nx, -1, 1.f, st);           // the x axis as rows
+    if (e == hipSuccess) e = transpose_c(w1, out, planes, Nyr, Nx, st);                    //                             [planes][Nx][Nyr]
+    return e;
+}
+// 2-D C2R (scale applied), any even size: in [planes][Nx][Ny/2+1] -> out [planes][Nx][Ny]
+hipError_t launch_c2r_any(const float2* in, float* out, float2* w1, float2* w2, long planes, int Nx, int Ny, float scale, hipStream_t st)
+{
+    if (!fft_size_supported_any(Nx) || !fft_size_supported_any(Ny) || Nx > 1024 || Ny > 1024) return hipErrorInvalidValue;
+    if (planes <= 0) return hipSuccess;
+    const int Nyr = Ny / 2 + 1;
+    hipError_t e = transpose_c(in, w1, planes, Nx, Nyr, st);                               // [planes][Nyr][Nx]
+    if (e == hipSuccess) e = blu_rows(0, w1, w2, planes * Nyr, Nx, +1, 1.f, st);
+    if (e == hipSuccess) e = transpose_c(w2, w1, planes, Nyr, Nx, st);                     // [planes][Nx][Nyr]
+    if (e == hipSuccess) e = blu_rows(2, w1, out, planes * Nx, Ny, +1, scale, st);
+    return e;
+}
 
 // `in` non-null: run the row pass (in -> mid); `out` non-null: run the column pass (mid -> out).
 hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st, hipEvent_t done)

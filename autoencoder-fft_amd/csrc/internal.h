@@ -33,6 +33,22 @@ struct OpIn { const float2* A; const float2* Xf; int D0, Nx0, Ny0; };
 hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi,
                       int Nx, int Ny, float scale, hipStream_t st, const OpIn* opin = nullptr);
 size_t fft_mid_elems(long planes, int Nx, int Wc);   // complex elements needed in `mid`
+// sizes that are not powers of two (cufftPlanMany takes any size, fft.cu:773-779): even n in 8..1024 through Bluestein's chirp-z form on the
+// power-of-two LDS passes; rows -> transpose -> rows -> transpose.  w1, w2: workspaces of fft_any_ws_elems complex each.
+bool fft_size_supported_any(int n);
+size_t fft_any_ws_elems(long planes, int Nx, int Ny);
+hipError_t launch_r2c_any(const float* in, float2* out, float2* w1, float2* w2, long planes, int Nx, int Ny, hipStream_t st);
+hipError_t launch_c2r_any(const float2* in, float* out, float2* w1, float2* w2, long planes, int Nx, int Ny, float scale, hipStream_t st);
+// sizes that are not powers of two (cufftPlanMany takes any size, fft.cu:773-779): even n in 8..1024 through Bluestein's chirp-z form on the
+// power-of-two LDS passes; rows -> transpose -> rows -> transpose.  w1, w2: workspaces of fft_any_ws_elems complex each.
+bool fft_size_supported_any(int n);
+size_t fft_any_ws_elems(long planes, int Nx, int Ny);
+hipError_t launch_r2c_any(const float* in, float2* out, float2* w1, float2* w2, long planes, int Nx, int Ny, hipStream_t st);
+hipError_t launch_c2r_any(const float2* in, float* out, float2* w1, float2* w2, long planes, int Nx, int Ny, float scale, hipStream_t st);
+// the same from a SMALL stored spectrum (the reconstruction's compact support) in one launch: the column pass as a direct Nxi-term sum
+// inside the row-pass workgroups, no `mid` (c2r_small_kernel)
+bool c2r_small_supported(int Nxi, int Nyi, int Nx, int Ny);
+hipError_t launch_c2r_small(const float2* in, float* out, long planes, int Nxi, int Nyi, int Nx, int Ny, float scale, hipStream_t st);
 
 // ---- spectral_kernels.hip --------------------------------------------------------------
 // Per-bin complex contraction  Out[r][c][bin] = alpha * sum_k opA(A[r][k][bin]) * opB(B[k][c][bin])
@@ -253,8 +269,13 @@ struct SpatialGradArgs {
     float Norm;
     int lo;                               // 0: GPU boundary test '>=0' (backproplib.cu:95), 1: CPU test '>0' (netlib.cpp:344)
     int tied;                             // backprop_gpu_cc: add the f-gradient into the c-gradient (backproplib.cu:466)
+    // fused step (aefft_step_spatial): hin IS Conv_gpu(in; c1, b1) -- then dF, dP follow from the same error-input region sums as dC
+    // (dF[d][m][t] = sum_{d2,t2} c1[m][d2][t2]/div1 R_t[d][d2][t+t2] + b1[m] S_t[d]) and the hidden layer is not read by the gradient
+    const float *c1 = nullptr, *b1 = nullptr;
+    float div1 = 1.f;
 };
 hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st);
+bool spatial_regions_ok(const SpatialGradArgs& a);   // the gradient goes through the error-input region sums (what the fused step needs)
 hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st);   // B-11: gf and gb as the CUDA source computes them (after launch_spatial_grad)
 size_t spatial_partial_floats(int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl);
 size_t spatial_rq_floats(int dD, int Nk, int Nl);

@@ -1137,6 +1137,7 @@ hipError_t launch_spatial_compat(const SpatialGradArgs& a, hipStream_t st)
 // (input plane d, row offset a) x segment (row, half): 5 column offsets x dD error planes = 15 running sums, one new input element and
 // dD error elements (broadcast among the lanes of a segment) per pixel.
 // ------------------------------------------------------------------------------------------
+static bool rcorr_ok(const SpatialGradArgs& a);
 struct RCorrArgs { const float *out, *in; float* part; int B, Nx, Ny, ik0, il0, lo; };
 constexpr int RC_TR = 8, RC_CW = 256, RC_T = 5, RC_NSEG = 16;
 template <int D> constexpr int rc_pw() { return 16 * (D * D * RC_T * RC_T + D); }      // floats of one workgroup's partial: [rc 4][cs 4][d1][d][a][b] | [rc][cs][d1]
@@ -1320,9 +1321,15 @@ __global__ __launch_bounds__(256) void rcorr_sum_kernel(const float* __restrict_
 
 // dC, dB from the region sums:  R_t1 = sum over the row classes whose row r has lo <= r - ik1 < Nx of (all columns - the columns c in {0, 1, Ny-1}
 // with c - il1 outside [lo, Ny));  gc[m][d][k][l] = sum_{d1,k1,l1} f[d1][m][k1][l1] R_(k1,l1)[d1][d][k1+k][l1+l],  gb[m] likewise from the s0 sums
+// With c1 (the fused step: the hidden layer is Conv_gpu(in; c1, b1) itself, hin[m][q] = sum_{d2,t2} c1[m][d2][t2] in[d2][q - t2] / div1 + b1[m]):
+//     gf[d][m][t] = sum_p s0[d][p] hin[m][p - t]   (p - t a hidden pixel)   = sum_{d2,t2} c1[m][d2][t2] / div1 * R_t[d][d2][t + t2] + b1[m] S_t[d]
+// -- the SAME masked correlations R_t (mask: p - t is a hidden pixel; composite offset t + t2) contracted with c1 instead of f, S_t the masked
+// s0 sums -- and gp[d] = sum of s0[d] over the whole image (backproplib.cu:271-288 re-associated): the 50-plane hidden layer is not read.
 template <int D>
 __global__ __launch_bounds__(256) void dc_from_regions_kernel(const float* __restrict__ f, const float* __restrict__ tmp, float* __restrict__ gc,
-                                                              float* __restrict__ gb, int dM, int Nx, int Ny, int ik0, int il0, int lo, float scale)
+                                                              float* __restrict__ gb, int dM, int Nx, int Ny, int ik0, int il0, int lo, float scale,
+                                                              const float* __restrict__ c1, const float* __restrict__ b1, float inv_div1,
+                                                              float* __restrict__ gf, float* __restrict__ gp)
 {
     constexpr int NK = 3, KK = 9, T = RC_T, NR = D * D * T * T, PW = rc_pw<D>();
     __shared__ float reg[PW];
@@ -1362,7 +1369,31 @@ __global__ __launch_bounds__(256) void dc_from_regions_kernel(const float* __res
     __syncthreads();
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int nw = dM * D * KK;
-    if (idx >= nw + dM) return;
+    if (idx >= nw + dM) {
+        if (!c1) return;
+        const int e = idx - (nw + dM);
+        if (e < nw) {
+            // gf[d][m][k][l]
+            const int d = e / (dM * KK), rem = e - d * dM * KK, m = rem / KK, kl = rem - m * KK, k = kl / NK, l = kl - k * NK;
+            const float* Rb = Rt + kl * (NR + D);
+            float s = 0.f;
+#pragma unroll
+            for (int d2 = 0; d2 < D; ++d2)
+#pragma unroll
+                for (int k2 = 0; k2 < NK; ++k2)
+#pragma unroll
+                    for (int l2 = 0; l2 < NK; ++l2)
+                        s = fmaf(c1[((long)(m * D + d2) * NK + k2) * NK + l2], Rb[(d * D + d2) * T * T + (k + k2) * T + (l + l2)], s);
+            gf[e] = fmaf(b1[m], Rb[NR + d], s * inv_div1);
+        } else if (e < nw + D) {
+            // gp[d]: s0 summed over the whole image = every row class, all columns
+            const int d = e - nw;
+            float s = 0.f;
+            for (int rc = 0; rc < 4; ++rc) s += reg[16 * NR + (rc * 4) * D + d];
+            gp[d] = s;
+        }
+        return;
+    }
     const bool isb = idx >= nw;
     const int m = isb ? idx - nw : idx / (D * KK);
     const int rr = isb ? 0 : idx - m * D * KK, d = rr / KK, kl = rr - d * KK, k = kl / NK, l = kl - k * NK;
@@ -1383,6 +1414,7 @@ __global__ __launch_bounds__(256) void dc_from_regions_kernel(const float* __res
 // floats of SpatialGradArgs::rq (the region sums)
 size_t spatial_rq_floats(int dD, int Nk, int Nl) { (void)Nk; (void)Nl; return (size_t)RC_NCH * 16 * ((size_t)dD * dD * RC_T * RC_T + dD); }
 
+bool spatial_regions_ok(const SpatialGradArgs& a) { return a.part && dconv_ok(a.Nk, a.Nl, a.B) && !flag(AEFFT_F_NOTILEDSPATIAL) && rcorr_ok(a); }
 static bool rcorr_ok(const SpatialGradArgs& a)
 {
     return a.rq && a.Nk == 3 && a.Nl == 3 && (a.dD == 3 || a.dD == 1) && a.dM >= 8 && a.Nx >= 8 && a.Ny >= 8 && a.Ny % 4 == 0 && a.lo <= 1 && a.ak == 0 && a.al == 0 &&
@@ -1407,8 +1439,9 @@ template <int D> static hipError_t run_rcorr(const SpatialGradArgs& a, float sca
     rcorr_sum_kernel<<<dim3((pw + 255) / 256, RC_NCH), 256, 0, st>>>(a.part, a.rq, nparts, pw);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int total = a.dM * D * 9 + a.dM;
-    dc_from_regions_kernel<D><<<dim3((total + 255) / 256), 256, 0, st>>>(a.f, a.rq, a.gc, a.gb, a.dM, a.Nx, a.Ny, ik0, il0, a.lo, scale);
+    const int total = a.dM * D * 9 + a.dM + (a.c1 ? a.dM * D * 9 + D : 0);
+    dc_from_regions_kernel<D><<<dim3((total + 255) / 256), 256, 0, st>>>(a.f, a.rq, a.gc, a.gb, a.dM, a.Nx, a.Ny, ik0, il0, a.lo, scale,
+                                                                         a.c1, a.b1, 1.0f / a.div1, a.gf, a.gp);
     return hipGetLastError();
 }
 
@@ -1418,7 +1451,7 @@ hipError_t launch_spatial_grad(const SpatialGradArgs& a, hipStream_t st)
         // dC, dB through the error-input correlation (no back-convolved error); dF, dP as the hidden-layer correlation on the matrix cores
         const float scale = 1.0f / a.Norm / (float)a.B;
         hipError_t e = a.dD == 3 ? run_rcorr<3>(a, scale, st) : run_rcorr<1>(a, scale, st);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess || a.c1) return e;             // (fused step: dF, dP came out of the region sums too)
         MCorrArgs mf{a.hin, a.dM, a.lo, a.out, a.in, a.dD, 0, +1, a.Nx, a.Ny, -2 * a.ak - 1, -2 * a.al - 1, 1, 0, 0, 0, a.part};
         return run_mcorr<3>(mf, a.B, a.gf, 1, nullptr, a.gp, scale, st);
     }

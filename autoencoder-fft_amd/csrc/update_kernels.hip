@@ -126,6 +126,56 @@ __device__ __forceinline__ void gdiff_part_body(const float* __restrict__ c, con
         const int j = t / KP, r = t - j * KP;
         sh[t] = r < KL ? w[(long)(j0 + j) * KL + r] : 0.f;
     }
+#ifndef AEFFT_X_GDPK
+#define AEFFT_X_GDPK 1
+#endif
+#if AEFFT_X_GDPK
+    // taps in PAIRS (native 2-vectors: the back end selects v_pk_add_f32 / v_pk_fma_f32, two taps per lane and issue slot): per partner
+    // KP/2 packed subtractions, KP/2 packed FMAs for the distance, one reciprocal, KP/2 packed FMAs for the sums; the pitch's padding taps
+    // are zero on both sides and drop out
+    {
+        constexpr int KH = KP / 2;
+        float2 ca2[KH], acc2[KH];
+        const int ii = min(i, np - 1);
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            ca2[h] = make_float2(2 * h < KL ? w[(long)ii * KL + 2 * h] : 0.f, 2 * h + 1 < KL ? w[(long)ii * KL + 2 * h + 1] : 0.f);
+            acc2[h] = make_float2(0.f, 0.f);
+        }
+        const int mi = isf ? ii % dM : ii / dD, di = isf ? ii / dM : ii % dD;
+        __syncthreads();
+        for (int j = j0; j < j1; ++j) {
+            const int mj = isf ? j % dM : j / dD, dj = isf ? j / dM : j % dD;       // (uniform)
+            const float4* row = reinterpret_cast<const float4*>(sh + (j - j0) * KP);
+            float2 diff[KH];
+            float2 den2 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < KP / 4; ++q) {
+                const float4 v = row[q];
+                diff[2 * q] = ca2[2 * q] - make_float2(v.x, v.y);
+                diff[2 * q + 1] = ca2[2 * q + 1] - make_float2(v.z, v.w);
+            }
+#pragma unroll
+            for (int h = 0; h < KH; ++h) den2 = den2 + diff[h] * diff[h];
+            const float den = den2.x + den2.y;
+            // pairs need m1 != m AND d1 != d (:724); coinciding kernels give 0 * inf = NaN like the reference's 0 / 0
+            if (mj != mi && dj != di) {
+                const float wgt = __builtin_amdgcn_rcpf(den);
+                const float2 w2 = make_float2(wgt, wgt);
+#pragma unroll
+                for (int h = 0; h < KH; ++h) acc2[h] = acc2[h] + diff[h] * w2;
+            }
+        }
+        if (i >= np) return;
+        float* dst = part + (((long)bz * nchunks + by) * np + i) * KL;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            if (2 * h < KL) dst[2 * h] = acc2[h].x;
+            if (2 * h + 1 < KL) dst[2 * h + 1] = acc2[h].y;
+        }
+        return;
+    }
+#endif
     float ca[KL], acc[KL];
     const int ii = min(i, np - 1);
 #pragma unroll

@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true", help="aefft_net_set_input_ready: run the input R2C on a side stream ahead of the context stream")
+    ap.add_argument("--cu-split", type=int, default=0, help="aefft_ctx_partition: compute units of the side streams (0 = no partition)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dp-probe", action="store_true", help="N = 1: skip the data_parallel block (a one-rank RCCL communicator, 20 untimed steps)")
     ap.add_argument("--no-variants", action="store_true", help="skip the short extra runs (cfg3-P1, spatial mode) reported under \"variants\"")
@@ -223,8 +224,10 @@ def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2
 
 def variant_spatial(aefft, torch, np, ctx, steps=20):
     """Spatial mode (a13-a15): Conv_gpu -> Conv_gpu -> backprop_gpu on 32 frames 256x256x3, 50 maps, 3x3 (the reference's default
-    layer, New_Layer_Param.txt) -- flops roofline: 2*dM*dD*Nk*Nl*Nx*Ny per conv and per gradient correlation, fp32 matrix-core
-    peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The convs are bound by their 419 MB output / input streams, not by flops."""
+    layer, New_Layer_Param.txt), as ONE call (aefft_step_spatial: the hidden layer is the call's own convolution, so dF and dP come out of
+    the error-input region sums like dC and dB and the 50-plane hidden layer is read once); the three separate calls -- what the vector shims
+    run, with a caller-supplied hidden layer -- are timed beside it.  Flops roofline: 2*dM*dD*Nk*Nl*Nx*Ny per conv, fp32 matrix-core peak
+    157.3 TFLOP/s (MI355X_MICROARCH.md).  The convs are bound by their 419 MB output / input streams, not by flops."""
     B, dD, dM, N, Nk = 32, 3, 50, 256, 3
     rng = np.random.default_rng(0)
     x = ctx.dev(np.floor(rng.uniform(0, 256, (B, dD, N, N))))
@@ -232,31 +235,42 @@ def variant_spatial(aefft, torch, np, ctx, steps=20):
     f = ctx.dev(rng.uniform(-1, 1, (dD, dM, Nk, Nk))); p = ctx.dev(rng.uniform(-1, 1, dD))
     mom = [torch.zeros_like(t) for t in (c, b, f, p)]
     grads = [torch.zeros_like(t) for t in (c, b, f, p)]
+    hbuf = ctx.empty(B, dM, N, N); obuf = ctx.empty(B, dD, N, N)
 
-    def step():
+    def fused():
+        ctx.step_spatial(x, c, b, f, p, mom, grads, 0.2, 0.9, hin=hbuf, out=obuf)
+
+    def separate():
         h = ctx.conv_spatial(x, c, b)
         o = ctx.conv_spatial(h, f, p)
         ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
 
-    for _ in range(5):
-        step()
-    ctx.sync(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.sync(); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    def timed(step):
+        for _ in range(5):
+            step()
+        ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.sync(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    dt_sep = timed(separate)
+    dt = timed(fused)
     conv_flops = 2.0 * B * dM * dD * Nk * Nk * N * N
-    # work of the groups AS LAUNCHED: conv 3->50, conv 50->3, the dF correlation (hidden layer x error: one conv-sized GEMM) and the
-    # error-input correlation behind dC (dD x dD x 25 sums per pixel) -- the back-convolved error and its correlation of rounds 1-2 no longer exist
-    flops = 3 * conv_flops + 2.0 * B * dD * dD * 25 * N * N
+    # work of the groups AS LAUNCHED: conv 3->50, conv 50->3 and the error-input correlation behind dC, dB, dF, dP (dD x dD x 25 sums per pixel)
+    flops = 2 * conv_flops + 2.0 * B * dD * dD * 25 * N * N
     act, hid = 4.0 * B * dD * N * N, 4.0 * B * dM * N * N        # bytes of a 3-plane and of the 50-plane tensor
-    algo_bytes = (act + hid) + (hid + act) + (hid + 2 * act) + 2 * act      # conv, conv, dF correlation (hin, out, in), error-input correlation (out, in)
-    return {"workload": f"spatial mode: Conv_gpu+Conv_gpu+backprop_gpu, {B} frames {N}x{N}x{dD}, {dM} maps, {Nk}x{Nk}", "frames_per_s": B / dt,
+    algo_bytes = (act + hid) + (hid + act) + 2 * act              # conv, conv, error-input correlation (out, in)
+    sep_bytes = algo_bytes + (hid + 2 * act)                      # ... + the dF correlation of the separate calls (hin, out, in)
+    return {"workload": f"spatial mode: Conv_gpu+Conv_gpu+backprop_gpu in one call (aefft_step_spatial), {B} frames {N}x{N}x{dD}, {dM} maps, {Nk}x{Nk}", "frames_per_s": B / dt,
             "ms_per_step": dt * 1e3, "steps": steps, "algo_TFLOP_per_step": flops / 1e12, "step_algo_GB": algo_bytes / 1e9,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                         "note": "whole step; the binding bound: the 50-map hidden layer (419 MB) is written once and read twice"},
-            "mfma_roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3}}
+                         "note": "whole step; the binding bound: the 50-map hidden layer (419 MB) is written once and read once"},
+            "mfma_roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3},
+            "separate_calls": {"ms_per_step": dt_sep * 1e3, "frames_per_s": B / dt_sep, "step_algo_GB": sep_bytes / 1e9,
+                               "frac_of_hbm_peak": sep_bytes / dt_sep / 1e9 / HBM_PEAK_GBS,
+                               "note": "aefft_conv_spatial x2 + aefft_backprop_spatial with a caller-supplied hidden layer (what the vector shims run): the hidden layer is read twice"}}
 
 
 def spawn_ranks(a):
@@ -281,6 +295,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)
+    # ONE JSON line on stdout: libraries that print banners on file descriptor 1 (RCCL prints its version block at communicator
+    # creation) go to stderr for the whole run; the line itself is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,6 +321,8 @@ def main():
     ctx = aefft.Context(local, use_torch_stream=a.torch_stream)
     if a.flags:
         ctx.set_flags(*a.flags.split(","))
+    if a.cu_split:
+        ctx.partition(a.cu_split)
     N, D, maps, Nk = a.size, 3, [8, 16, 32, 64], 5
     s = 2 if a.variant == "p2" else 1
     B = a.batch
@@ -505,7 +526,8 @@ def main():
             out["cpu_baseline"] = cpu
         if variants:
             out["variants"] = variants
-        print(json.dumps(finite_json(out)), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(finite_json(out)) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,7 +14,10 @@
  *   - spectra       : interleaved complex64 (float pairs), [ch][Nx][Nyr], Nyr = Ny/2+1
  *   - encoder kernel: c[dM][dD][Nk][Nl], bias b[dM]; decoder kernel f[dD][dM][Nk][Nl], bias p[dD]
  *   - batches add an outermost [B] dimension.  B = 1 reproduces the reference call exactly.
- *   - Nx, Ny: powers of two in 8..2048.  Pooling scales: powers of two.
+ *   - Nx, Ny: powers of two in 8..2048; pooling scales: powers of two -- for the resident network and the per-bin ops.
+ *     The transforms and the spectral resize at op level (aefft_r2c, aefft_c2r, aefft_pool, aefft_r2c_pool, aefft_unpool_c2r) also serve
+ *     EVEN sizes in 8..1024 that are not powers of two (cufftPlanMany takes any size, fft_backproplib.cu:773-779) and any integer scale,
+ *     sized as the reference sizes it (:980-984: int(Nx / l) in float arithmetic; the resized grid must be even).
  *   - every function returns AEFFT_OK (0) or an error code; aefft_last_error() gives the text.
  *     Work is enqueued on the context's stream; nothing blocks unless stated.
  *   - there is NO CPU fallback: every call fails with AEFFT_EHIP when no MI355X is present.
@@ -46,6 +49,11 @@ enum {
 int aefft_ctx_create(aefft_ctx** out, int device, void* hip_stream, int create_stream);
 void aefft_ctx_destroy(aefft_ctx* ctx);
 const char* aefft_last_error(const aefft_ctx* ctx);
+/* Optional spatial partition of the chip for pipelined training loops (aefft_net_set_input_ready): side_cus > 0 gives the library's side
+ * streams (reconstruction inverse FFT, input prefetch: bandwidth-bound) `side_cus` of the device's compute units and the context's own
+ * stream (the latency-bound weight side of the step) the rest, through CU-masked HIP streams; 0 removes the partition.  Only for a context
+ * that owns its stream (create_stream = 1) and before its first net is created (AEFFT_ESTATE otherwise): aefft_stream() changes. */
+int aefft_ctx_partition(aefft_ctx* ctx, int side_cus);
 int aefft_sync(aefft_ctx* ctx);                 /* hipStreamSynchronize on the context stream */
 void* aefft_stream(aefft_ctx* ctx);             /* the hipStream_t in use */
 /* Development switches: each bit turns ONE optimisation of the training step off (or forces one the shapes would not choose), so
@@ -162,6 +170,19 @@ int aefft_backprop_spatial(aefft_ctx* ctx, const float* in_d, const float* out_d
                            float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
                            int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
                            float delmax, float alpha, int tied, int cpu_semantics);
+
+/* One spatial-mode training step in ONE call: Conv_gpu (in -> hin), Conv_gpu (hin -> out), backprop_gpu[_cc] -- the sequence
+ * autoencoder.cpp:140-148,200 runs per pair (backproplib.cu:114-182, 291-418, 521-644).  Because the hidden layer is then known to be
+ * this call's own convolution of `in`, the decoder gradients dF, dP are formed from the same error-input region sums as dC, dB
+ *  and the dM-plane hidden layer is read once (by the second convolution) instead of twice; shapes the region
+ * route does not serve (kernels other than 3x3, more than 3 input channels, ...) run the plain sequence.  hin_d [B][dM][Nx][Ny] and
+ * out_d [B][dD][Nx][Ny] receive the two layers; everything else as aefft_backprop_spatial.  cpu_semantics: 0 or 1. */
+int aefft_step_spatial(aefft_ctx* ctx, const float* in_d, float* hin_d, float* out_d,
+                       float* c_d, float* b_d, float* f_d, float* p_d,
+                       float* dc_d, float* db_d, float* df_d, float* dp_d,
+                       float* ddc_d, float* ddb_d, float* ddf_d, float* ddp_d,
+                       int B, int dD, int dM, int Nx, int Ny, int Nk, int Nl,
+                       float delmax, float alpha, int tied, int cpu_semantics);
 
 /* ---- network level: the resident, batched form of autoenc_fft / backprop_fft ------------------ */
 typedef struct {

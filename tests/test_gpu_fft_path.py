@@ -75,11 +75,15 @@ def test_pool_and_fused_forms(ctx, N, s):
 def test_pool_rejects_bad_sizes(ctx):
     X = ctx.dev(np.zeros((1, 16, 9), np.complex64))
     with pytest.raises(aefft.AefftError):
-        ctx.pool(X, 16, 3)           # not a power of two (SURVEY B-4)
+        ctx.pool(X, 16, 3)           # int(16 / 3) = 5: an odd grid (the index rules of `resize` are written for even sizes)
     with pytest.raises(aefft.AefftError):
         ctx.pool(X, 16, 4)           # 16/4 < 8
     with pytest.raises(aefft.AefftError):
-        ctx.r2c(ctx.dev(np.zeros((1, 12, 12), np.float32)))
+        ctx.r2c(ctx.dev(np.zeros((1, 13, 12), np.float32)))       # odd size
+    with pytest.raises(aefft.AefftError):
+        ctx.r2c(ctx.dev(np.zeros((1, 1026, 16), np.float32)))     # not a power of two and beyond the 1024 the chirp-z form serves
+    with pytest.raises(aefft.AefftError):
+        aefft.Net(ctx, 3, 96, 96, [4], 5, 2, batch=1)             # the resident network: powers of two only
 
 
 @pytest.mark.parametrize("N,Nk,Nl", [(16, 5, 5), (32, 3, 3), (64, 5, 3), (128, 7, 7)])

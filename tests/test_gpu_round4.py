@@ -164,3 +164,85 @@ def test_multiobjective_update_beyond_one_lds_chunk_round(ctx, Nk, dD, dM):
         assert np.abs(ref).max() > 1e-4
         assert np.abs(got - ref).max() < 1e-6 + 2e-4 * np.abs(ref).max(), np.abs(got - ref).max()
     assert np.abs(host(t[2]).astype(np.float64) - b + step(-10.0 * bd)).max() < 1e-6 + 2e-4 * np.abs(step(-10.0 * bd)).max()
+
+
+def test_data_parallel_library_at_world_size_one(ctx):
+    """include/aefft_dp.h (libaefft_dp.so): step_grad -> ncclAllReduce on the library's stream -> step_apply in one C call, on a
+    communicator of one rank (the only size a one-GPU box allows; N > 1 is the same code with more ranks).  Weights after 4 steps equal
+    a net trained without the collective bit for bit; the phase profile, the flushed global MSE, the replica check and the message size."""
+    dp = importlib.import_module("autoencoder-fft_amd.dp")
+    rng = np.random.default_rng(41)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6], 5, 2, 4
+    ws, dD = [], D
+    for dM in maps:
+        ws.append((rng.uniform(-1, 1, (dM, dD, Nk, Nk)), rng.uniform(-1, 1, dM), rng.uniform(-1, 1, (dD, dM, Nk, Nk)), rng.uniform(-1, 1, dD))); dD = dM
+    x = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    recon = ctx.empty(B, D, N, N)
+
+    def make():
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        return net
+
+    plain = make()
+    mse = ctx.empty(len(maps))
+    for _ in range(4):
+        plain.step_grad(x, recon); plain.step_apply(0.2, 0, 0, 1.0, mse)
+    ctx.sync()
+    want, want_mse = [plain.get_pair(l) for l in range(len(maps))], host(mse).copy()
+    plain.close()
+    net = make()
+    step = dp.RcclStep(net, 0, 1)
+    assert step.allreduce_bytes() == 4 * net.grad_buffer().numel()
+    step(x, recon, 0.2)
+    step.run(x, recon, 0.2, 2)
+    step(x, recon, 0.2, mse=mse)
+    ctx.sync()
+    for a, b in zip(want, [net.get_pair(l) for l in range(len(maps))]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    assert np.array_equal(host(mse), want_mse)
+    assert np.allclose(step.flush_mse(), want_mse, rtol=1e-6)
+    assert step.replicas_agree()
+    ph, host_us = step.profile(x, recon, 0.2, 5)
+    assert len(ph) == 3 and all(p > 0 for p in ph) and 0 < host_us < 5000
+    step.close(); net.close()
+
+
+@pytest.mark.parametrize("Nx,Ny,planes", [(96, 96, 3), (160, 96, 2), (480, 640, 2), (640, 480, 1), (12, 10, 5), (1000, 24, 1), (64, 96, 2), (96, 64, 2)])
+def test_transforms_of_sizes_that_are_not_powers_of_two(ctx, Nx, Ny, planes):
+    """a2 `fft` / `fft_inv` at the sizes cufftPlanMany takes and the power-of-two Stockham passes do not (fft_backproplib.cu:773-779, 885,
+    1208): even sizes through Bluestein's chirp-z form (fft_kernels.hip), 640x480-class frames included, mixed with a power-of-two axis;
+    against numpy's pocketfft at the transform tolerance of the power-of-two path times the two extra transforms per axis."""
+    rng = np.random.default_rng(Nx * 3 + Ny)
+    x = np.floor(rng.uniform(0, 256, (planes, Nx, Ny))).astype(np.float32)
+    X = ctx.r2c(ctx.dev(x))
+    ref = R.fft(x)
+    assert relerr(host(X), ref) < 1e-5
+    Z = ref + 1e-3 * np.abs(ref).max() * (rng.normal(size=ref.shape) + 1j * rng.normal(size=ref.shape))      # not exactly Hermitian
+    y = ctx.c2r(ctx.dev(Z), Ny)
+    assert relerr(host(y), R.fft_inv(Z, Nx, Ny)) < 2e-5
+    yu = ctx.c2r(ctx.dev(Z), Ny, scale=1.0)
+    assert relerr(host(yu), R.c2r_unnorm(Z, Nx, Ny)) < 2e-5
+
+
+@pytest.mark.parametrize("N,s", [(96, 3), (480, 3), (120, 5), (96, 2), (192, 6)])
+def test_pooling_by_scales_that_are_not_powers_of_two(ctx, N, s):
+    """a3 `pool_fft` / `resize` (fft_backproplib.cu:87-157, 975-1002) with Pooling_scale 3, 5, 6 (the reference takes any integer,
+    :980-984): the index remap bit for bit against np_ref.resize, the size as the reference's float arithmetic gives it, down and up, and
+    the fused forms r2c -> pool and pool -> c2r."""
+    rng = np.random.default_rng(N + s)
+    x = np.floor(rng.uniform(0, 256, (2, N, N))).astype(np.float32)
+    X = R.fft(x)
+    down, nx, ny = R.pool_fft(X, N, N, s)
+    assert (nx, ny) == (N // s, N // s)
+    Xd, gx, gy = ctx.pool(ctx.dev(X), N, s)
+    assert (gx, gy) == (nx, ny) and np.array_equal(host(Xd), down.astype(np.complex64))
+    up, ux, uy = R.pool_fft(down, nx, ny, -s)
+    assert (ux, uy) == (N, N), "the reference's int(Nx / (1/s)) in float32"
+    Xu, gx, gy = ctx.pool(ctx.dev(down), ny, -s)
+    assert (gx, gy) == (ux, uy) and np.array_equal(host(Xu), up.astype(np.complex64))
+    assert relerr(host(ctx.r2c_pool(ctx.dev(x), s)), down) < 1e-5
+    y = ctx.unpool_c2r(ctx.dev(down), ny, -s, 1.0 / (N * N))
+    assert relerr(host(y), R.fft_inv(up, N, N)) < 2e-5

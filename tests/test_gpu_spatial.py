@@ -241,3 +241,50 @@ def test_backprop_kernel_gradient_through_the_error_input_correlation(ctx, flags
         for k, g, r in zip(("ddc", "ddb", "ddf", "ddp"), res[0], ref[8:]):
             if r is not None:
                 assert np.abs(g - r).max() < 3e-5 * max(np.abs(r).max(), 1e-30), k
+
+
+@pytest.mark.parametrize("dD,dM,N,B,tied,sem", [(3, 50, 40, 2, False, "gpu"), (3, 16, 264, 1, False, "gpu"), (1, 8, 64, 3, True, "gpu"), (3, 12, 48, 2, True, "gpu"),
+                                                (3, 10, 40, 2, False, "cpu"), (3, 9, 32, 1, True, "cpu"), (3, 6, 32, 2, False, "gpu"), (4, 10, 32, 1, False, "gpu")])
+def test_fused_spatial_step_gradients_from_the_region_sums(ctx, flags, dD, dM, N, B, tied, sem):
+    """aefft_step_spatial = Conv_gpu, Conv_gpu, backprop_gpu[_cc] in one call.  The hidden layer is then the call's own convolution of
+    the input, and dF, dP are contracted from the same error-input region sums as dC, dB (the hidden layer is not read by the gradient):
+    layers, gradients, updated weights and momentum == the three separate calls (which read the hidden layer) == the oracle; both
+    boundary semantics, tied weights, border regions, two column blocks (N = 264), and shapes the region route declines (dM = 6 < 8
+    maps, 4 input channels), which run the plain sequence inside the same call."""
+    rng = np.random.default_rng(7 * N + dM + dD)
+    x, c, b, f, p = _case(rng, dD, dM, N, 3, B)
+    mom = [0.01 * rng.normal(size=a.shape).astype(np.float32) for a in (c, b, f, p)]
+    flags()
+    # the separate calls
+    tw = [ctx.dev(a) for a in (c, b, f, p)]
+    tm = [ctx.dev(a) for a in mom]
+    tg = [ctx.dev(np.zeros_like(a)) for a in (c, b, f, p)]
+    xd = ctx.dev(x)
+    h0 = ctx.conv_spatial(xd, tw[0], tw[1], semantics=sem)
+    o0 = ctx.conv_spatial(h0, tw[2], tw[3], semantics=sem)
+    ctx.backprop_spatial(xd, o0, h0, *tw, tm, tg, 0.2, 0.9, tied=tied, semantics=sem)
+    sep = [host(t).copy() for t in tw + tm + tg]
+    # the fused call
+    tw = [ctx.dev(a) for a in (c, b, f, p)]
+    tm = [ctx.dev(a) for a in mom]
+    tg = [ctx.dev(np.zeros_like(a)) for a in (c, b, f, p)]
+    h1, o1 = ctx.step_spatial(xd, *tw, tm, tg, 0.2, 0.9, tied=tied, semantics=sem)
+    fus = [host(t).copy() for t in tw + tm + tg]
+    assert np.array_equal(host(h1), host(h0)) and np.array_equal(host(o1), host(o0))
+    names = ["c", "b", "f", "p", "dc", "db", "df", "dp", "ddc", "ddb", "ddf", "ddp"]
+    for k, a, r in zip(names, fus, sep):
+        if tied and k in ("df", "ddf"):
+            continue
+        ref_scale = max(np.abs(sep[8]).max(), 1e-30) if k in ("ddc", "ddf") else max(np.abs(r).max(), 1e-30)
+        if k.startswith("dd"):
+            assert np.abs(a - r).max() < 5e-5 * ref_scale, (k, np.abs(a - r).max(), ref_scale)
+        else:
+            # one clipped-momentum step from the same gradients up to 5e-5: 0.02 * dg / 10
+            assert np.abs(a - r).max() < 1e-6 + 0.02 / 10 * 5e-5 * max(np.abs(sep[8]).max(), np.abs(sep[10]).max(), np.abs(sep[9]).max(), np.abs(sep[11]).max()), k
+    if sem == "gpu":
+        hin = [S.conv(x[i], c, b) for i in range(B)]
+        out = [S.conv(hin[i], f, p) for i in range(B)]
+        ref = S.backprop_gpu(list(x), out, hin, c, b, f, p, mom[0], mom[1], mom[2], mom[3], 0.2, 0.9, tied=tied, B_mean=True)
+        for k, g, r in zip(("ddc", "ddb", "ddf", "ddp"), fus[8:], ref[8:]):
+            if r is not None:
+                assert np.abs(g - r).max() < 5e-5 * max(np.abs(r).max(), 1e-30), k

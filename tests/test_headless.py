@@ -45,16 +45,19 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
     with open(os.path.join(d, "New_Layer_Param.txt"), "w") as fh:
         fh.write(f"M {M}\nLk {Lk}\nLl {Lk}\nS {S}\nrmax 1\n")      # rmax 1: keeps the added pair's burst in the smooth regime
     # key script, one key per frame: load weights, fft_l on, learning rate 0.2 -> 0.009 (eleven `5` keys), train pair 0, add a pair, save it
-    # (so the replay knows its rand()-initialised weights), five more `5` keys (0.009 -> 0.004), train the new pair.  Both bursts sit in the
-    # SMOOTH regime: the oracle's own float32 replay of burst 2 stays within 2 % of the weight tolerance below for every element (asserted),
-    # so the HIP path is held to that fixed tolerance, element by element.  The chaotic default-rate regime (del0 = 0.2) has its own tests
+    # (so the replay knows its rand()-initialised weights), fourteen more `5` keys (0.009 -> 0.0004), train the new pair.  Both bursts sit in the
+    # SMOOTH regime: the oracle's own float32 replay of the WHOLE SESSION (burst 1 in float32, the forward with its end weights, burst 2 in
+    # float32) ends within a tenth of the weight tolerance below for every element (asserted), so the HIP path is held to that fixed
+    # tolerance, element by element.  (At 0.004 for burst 2 the float32 session replay itself ends 4e-4 = 7 tolerances away in a few
+    # flat directions, although a replay that starts from the master's burst-1 weights stays at 1 % of the tolerance: the input of burst 2
+    # carries burst 1's rounding, and the criterion has to.)  The chaotic default-rate regime (del0 = 0.2) has its own tests
     # with the first-divergence criterion: tests/test_gpu_round2.py::test_default_rate_burst_..., tests/test_gpu_round4.py (300 steps).
-    script = "lg" + "5" * 11 + "1." + "ns" + "5" * 5 + "1." + "."
+    script = "lg" + "5" * 11 + "1." + "ns" + "5" * 14 + "1." + "."
     F = len(script)
     del0 = _del_after(script[:script.index('1')])
     assert 0.005 < del0 < 0.02
     del1 = _del_after(script[:script.rindex('1')])
-    assert 0.003 < del1 < 0.005
+    assert 0.0003 < del1 < 0.0005
     video = np.floor(rng.uniform(0, 256, (F, D, N, N))).astype(np.float32)
     video.tofile(os.path.join(d, "video.f32"))
     c0 = rng.uniform(-1, 1, (M, D, Nk, Nk)).astype(np.float32); b0 = rng.uniform(-1, 1, M).astype(np.float32)
@@ -83,10 +86,13 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
     lay, cf, _ = R.autoenc_fft(video[t_train1].astype(f64), net_c, net_b, [S, S, -S, -S])
     # pair 1: in = layers[3], out = layers[size-2-2] = layers[5]
     r1 = R.backprop_fft(lay[3], lay[3], lay[5], cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del1, n_iter=100)
-    # the oracle's own float32 replay of burst 2: the precondition of the fixed tolerance (smooth regime)
+    # the oracle's own float32 replay of the whole session: the precondition of the fixed tolerance (smooth regime)
     f32 = np.float32
-    r1_32 = R.backprop_fft(lay[3].astype(f32), lay[3].astype(f32), lay[5].astype(f32), cf[1], net_c[1], cf[2], net_c[2], net_b[1], net_b[2], del1,
-                           n_iter=100, dtype=f32)
+    lay0s, cf0s, _ = R.autoenc_fft(video[t_train0].astype(f32), [c0, f0], [b0, p0], [S, -S], dtype=f32)
+    r0_32 = R.backprop_fft(lay0s[1], lay0s[1], lay0s[3], cf0s[0], c0, cf0s[1], f0, b0, p0, del0, n_iter=100, dtype=f32)
+    ncs, nbs = [r0_32["c"], c1, f1, r0_32["f"]], [r0_32["b"], b1, p1, r0_32["p"]]
+    lays, cfs, _ = R.autoenc_fft(video[t_train1].astype(f32), ncs, nbs, [S, S, -S, -S], dtype=f32)
+    r1_32 = R.backprop_fft(lays[3], lays[3], lays[5], cfs[1], ncs[1], cfs[2], ncs[2], nbs[1], nbs[2], del1, n_iter=100, dtype=f32)
     printed = [float(ln.split("mse:")[1]) for ln in out.stdout.splitlines() if ln.startswith("n: ")]
     heads = [float(ln.split("mse fft:")[1]) for ln in out.stdout.splitlines() if ln.startswith("mse fft:")]
     assert len(printed) == 200 and len(heads) == 2, (len(printed), len(heads))
@@ -94,8 +100,9 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
     m0, m1 = np.array(r0["mse"], np.float64), np.array(r1["mse"], np.float64)
     # the MSE sequences the shims print (fft_backproplib.cu:1441,1464), every iteration of both bursts, at the stated MSE tolerance (6 printed digits)
     assert np.allclose(seq0, m0, rtol=2e-5), np.abs(seq0 / m0 - 1).max()
-    assert np.allclose(np.asarray(r1_32["mse"], np.float64), m1, rtol=2e-5), "burst 2 must sit in the smooth regime"
-    assert np.allclose(seq1, m1, rtol=2e-5), np.abs(seq1 / m1 - 1).max()
+    assert np.allclose(np.asarray(r1_32["mse"], np.float64), m1, rtol=1e-4), "burst 2 must sit in the smooth regime"
+    # (burst 2 starts from burst 1's END weights, which carry that burst's weight tolerance: its MSE level inherits ~2e-5 from the first value on)
+    assert np.allclose(seq1, m1, rtol=1e-4), np.abs(seq1 / m1 - 1).max()
     nets = lambda r: ([r0["c"], r["c"], r["f"], r0["f"]], [r0["b"], r["b"], r["p"], r0["p"]])
     lay_end, _, _ = R.autoenc_fft(video[F - 1].astype(f64), *nets(r1), [S, S, -S, -S])
 
@@ -112,7 +119,7 @@ def test_scripted_session_matches_oracle_replay(tmp_path):
         assert dw > 1e-3
         tol = 2e-5 + 1e-3 * dw
         if n in (1, 2):
-            # precondition: the float32 replay of the same burst keeps EVERY element within a tenth of the tolerance the HIP path is held to
+            # precondition: the float32 replay of the session keeps EVERY element within a tenth of the tolerance the HIP path is held to
             key = "c" if n == 1 else "f"
             assert np.abs(r1_32[key] - w).max() < 0.1 * tol, (key, np.abs(r1_32[key] - w).max(), tol)
         assert np.abs(got_w - w).max() < tol, (n, np.abs(got_w - w).max(), tol, dw)
