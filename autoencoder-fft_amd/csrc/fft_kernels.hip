@@ -58,15 +58,24 @@ bool fft_size_supported(int n) { return n >= 8 && n <= 2048 && (n & (n - 1)) == 
 // ------------------------------------------------------------------------------------------
 // complex helpers
 // ------------------------------------------------------------------------------------------
-// complex arithmetic on the native 2-vector (HIP_vector_type::operator+ etc. are element-wise on ext_vector_type(2)): the
-// back end selects v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers for the swizzles, two floats per
-// lane and issue slot (18 % fewer VALU instructions per radix-8 pass; the row kernels are not VALU-bound, so this is tidy-up)
+// complex arithmetic on the native 2-vector, two floats per lane and issue slot (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  The row and
+// column kernels are co-limited by their VALU instruction stream (rocprofv3 --pmc: VALUBusy 51-55 %), and what hipcc makes of a
+// complex product or of a rotation by +-i written on float2 is the packed arithmetic PLUS v_mov / v_xor instructions that build the swapped and
+// negated operand (92 of the 363 vector instructions of the 512-point row pass).  The VOP3P modifiers do that inside the arithmetic instruction --
+// op_sel / op_sel_hi pick which half of each source feeds the low / high result, neg_lo / neg_hi negate it -- so the products and the
+// rotate-and-add forms below are written as the instructions themselves: a complex product is two instructions, a +- i b is one.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f tov(float2 a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ float2 tof(v2f a) { return __builtin_bit_cast(float2, a); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    const float2 ax = make_float2(a.x, a.x), ay = make_float2(a.y, a.y), bs = make_float2(-b.y, b.x);
-    return ax * b + ay * bs;
+    v2f t, r;
+    const v2f av = tov(a), bv = tov(b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));                                        // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));       // + (-a.y b.y, a.y b.x)
+    return tof(r);
 }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // multiply by exp(DIR*i*pi/2): -i for the forward transform, +i for the inverse
@@ -74,6 +83,16 @@ template <int DIR> __device__ __forceinline__ float2 mul_i(float2 a)
 {
     return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
+// a + mul_i<DIR>(b) and a - mul_i<DIR>(b) in one instruction each
+template <int DIR> __device__ __forceinline__ float2 add_muli(float2 a, float2 b)
+{
+    v2f r;
+    const v2f av = tov(a), bv = tov(b);
+    if (DIR < 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));             // (a.x + b.y, a.y - b.x)
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));                     // (a.x - b.y, a.y + b.x)
+    return tof(r);
+}
+template <int DIR> __device__ __forceinline__ float2 sub_muli(float2 a, float2 b) { return add_muli<-DIR>(a, b); }
 template <int DIR> __device__ __forceinline__ float2 twid(int idx)
 {
     float2 w = g_tw[idx];
@@ -93,9 +112,10 @@ template <int DIR> struct Dft<2, DIR> {
 template <int DIR> struct Dft<4, DIR> {
     static __device__ __forceinline__ void run(float2* a)
     {
-        float2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
-        float2 t2 = cadd(a[1], a[3]), t3 = mul_i<DIR>(csub(a[1], a[3]));
-        a[0] = cadd(t0, t2); a[1] = cadd(t1, t3); a[2] = csub(t0, t2); a[3] = csub(t1, t3);
+        const float2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+        const float2 t2 = cadd(a[1], a[3]), d = csub(a[1], a[3]);
+        a[0] = cadd(t0, t2); a[2] = csub(t0, t2);
+        a[1] = add_muli<DIR>(t1, d); a[3] = sub_muli<DIR>(t1, d);
     }
 };
 template <int DIR> struct Dft<8, DIR> {
@@ -107,14 +127,13 @@ template <int DIR> struct Dft<8, DIR> {
         Dft<4, DIR>::run(o);
         const float c = 0.70710678118654752440f;
         // o[u] *= w8^u, w8 = exp(DIR*i*pi/4)
-        // w8 = (1 -+ i)/sqrt2, w8^3 = (-1 -+ i)/sqrt2:  o*w8 = c*(o + mul_i(o)),  o*w8^3 = c*(mul_i(o) - o)
-        const float2 cc = make_float2(c, c);
-        const float2 o1 = cc * (o[1] + mul_i<DIR>(o[1]));
-        const float2 o3 = cc * (mul_i<DIR>(o[3]) - o[3]);
-        float2 o2 = mul_i<DIR>(o[2]);
+        // w8 = (1 -+ i)/sqrt2, w8^3 = (-1 -+ i)/sqrt2:  o*w8 = c*(o + mul_i(o)),  o*w8^3 = -c*(o - mul_i(o)),  o*w8^2 = mul_i(o) (folded into the sums)
+        const float2 cc = make_float2(c, c), nc = make_float2(-c, -c);
+        const float2 o1 = cc * add_muli<DIR>(o[1], o[1]);
+        const float2 o3 = nc * sub_muli<DIR>(o[3], o[3]);
         a[0] = cadd(e[0], o[0]); a[4] = csub(e[0], o[0]);
         a[1] = cadd(e[1], o1);   a[5] = csub(e[1], o1);
-        a[2] = cadd(e[2], o2);   a[6] = csub(e[2], o2);
+        a[2] = add_muli<DIR>(e[2], o[2]); a[6] = sub_muli<DIR>(e[2], o[2]);
         a[3] = cadd(e[3], o3);   a[7] = csub(e[3], o3);
     }
 };
@@ -251,10 +270,11 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     // loads across the iterations of a load->use loop, which would serialise NV/NT memory round trips
     constexpr int NLD = NV / NT;
     static_assert(NV % NT == 0, "tile must be a whole number of float4 per thread");
-    const long vmax = (npairs - pair0) * (2 * N / 4) - 1;      // last valid float4 of this workgroup's chunk
+    const long left = (npairs - pair0) * (2 * N / 4) - 1;      // last valid float4 of this workgroup's chunk
+    const int vmax = left < NV - 1 ? (int)left : NV - 1;       // (32-bit index arithmetic per lane: the workgroup's chunk is NV float4s)
     float4 val[NLD];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) { const long v = tid + k * NT; val[k] = ld_stream(&src[v <= vmax ? v : vmax]); }      // (frames are read once)
+    for (int k = 0; k < NLD; ++k) { const int v = tid + k * NT; val[k] = ld_stream(&src[v <= vmax ? v : vmax]); }      // (frames are read once)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int v = tid + k * NT;
@@ -272,10 +292,11 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     __syncthreads();
     fft_lds<N, -1>(s + g * PL, t, tws);
 
-    const int half = Wc / 2;
+    // (Wc is a power of two: shifts, not the ~20-instruction expansion of a division by a run-time value, twice per item)
+    const int half = Wc / 2, hs = 31 - __builtin_clz(half);
     for (int it = tid; it < G * 2 * half; it += NT) {
-        const int gg = it / (2 * half), rem = it % (2 * half);
-        const int row = rem / half, k = (rem % half) * 2;
+        const int gg = it >> (hs + 1), rem = it & (2 * half - 1);
+        const int row = rem >> hs, k = (rem & (half - 1)) * 2;
         if (pair0 + gg >= npairs) continue;
         const float2* z = s + gg * PL;
         const float2 r0 = split_rows<N>(z, k, row), r1 = split_rows<N>(z, k + 1, row);
@@ -795,8 +816,8 @@ hipError_t launch_c2r_any(const float2* in, float* out, float2* w1, float2* w2, 
 // `in` non-null: run the row pass (in -> mid); `out` non-null: run the column pass (mid -> out).
 hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st, hipEvent_t done)
 {
-    if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxs > Nx || Nys > Ny || Nys < 8 || Nxs < 2 || (Nys & 1) || (Nxs & 1))
-        return hipErrorInvalidValue;
+    if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxs > Nx || Nys > Ny || Nys < 8 || Nxs < 2 || (Nys & (Nys - 1)) || (Nxs & 1))
+        return hipErrorInvalidValue;                     // (Nys a power of two: the row pass indexes its packed columns with shifts)
     if (planes <= 0) return hipSuccess;
     const int Wc = Nys / 2;
     const long npairs = planes * Nx / 2;
