@@ -238,19 +238,6 @@ template <int N> struct RowCfg {
     static constexpr int PL = pad_len(N);
 };
 
-// Hermitian split of Z = FFT(a + i*b): element k of row `row` (0: a, 1: b) in the packed layout
-// (k = 0 carries DC in .x and Nyquist in .y).
-template <int N> __device__ __forceinline__ float2 split_rows(const float2* z, int k, int row)
-{
-    if (k == 0) {
-        float2 z0 = z[pad_idx(0)], zh = z[pad_idx(N / 2)];
-        return row == 0 ? make_float2(z0.x, zh.x) : make_float2(z0.y, zh.y);
-    }
-    float2 zk = z[pad_idx(k)], zn = z[pad_idx(N - k)];
-    return row == 0 ? make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y))
-                    : make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-}
-
 template <int N>
 __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __restrict__ in, float2* __restrict__ mid,
                                                                    long npairs, int Wc)
@@ -264,44 +251,57 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     FftTw<N, -1> tws;
     tws.load(t);
 
-    constexpr int NV = G * 2 * N / 4;
+    // A thread loads the SAME four columns of both rows of a pair (two 16-byte loads per position, every load of the tile issued before the
+    // first LDS store: hipcc does not hoist loads across the iterations of a load->use loop) and writes four complete complex elements
+    // a + i*b -- consecutive in the padded layout, i.e. two ds_write2_b64 -- instead of eight 4-byte halves at stride 2.
+    constexpr int NPOS = G * (N / 4) / NT;                      // positions per thread (= 2 when NT = G*N/8)
+    static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of positions per thread");
     const float4* src = reinterpret_cast<const float4*>(in + pair0 * 2 * N);
-    // all global loads of the tile first (branch-free, clamped index), then the LDS scatter: hipcc does not hoist
-    // loads across the iterations of a load->use loop, which would serialise NV/NT memory round trips
-    constexpr int NLD = NV / NT;
-    static_assert(NV % NT == 0, "tile must be a whole number of float4 per thread");
-    const long left = (npairs - pair0) * (2 * N / 4) - 1;      // last valid float4 of this workgroup's chunk
-    const int vmax = left < NV - 1 ? (int)left : NV - 1;       // (32-bit index arithmetic per lane: the workgroup's chunk is NV float4s)
-    float4 val[NLD];
+    const int live = npairs - pair0 < G ? (int)(npairs - pair0) : G;      // row pairs of this workgroup that exist (uniform)
+    float4 va[NPOS], vb[NPOS];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) { const int v = tid + k * NT; val[k] = ld_stream(&src[v <= vmax ? v : vmax]); }      // (frames are read once)
+    for (int q = 0; q < NPOS; ++q) {
+        const int pos = tid + q * NT;
+        const int gg = pos / (N / 4), c4 = pos % (N / 4);
+        const int idx = gg < live ? gg * (2 * N / 4) + c4 : c4;           // (32-bit lane offsets; rows that do not exist re-read pair 0)
+        va[q] = ld_stream(&src[idx]);                                     // (frames are read once)
+        vb[q] = ld_stream(&src[idx + N / 4]);
+    }
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int v = tid + k * NT;
-        const int e = v * 4;
-        const int gg = e / (2 * N), o = e % (2 * N);
-        const int row = o / N, n0 = o % N;
-        if (pair0 + gg < npairs) {
-            float* dst = reinterpret_cast<float*>(s + gg * PL) + row;
-            dst[2 * pad_idx(n0)] = val[k].x;
-            dst[2 * pad_idx(n0 + 1)] = val[k].y;
-            dst[2 * pad_idx(n0 + 2)] = val[k].z;
-            dst[2 * pad_idx(n0 + 3)] = val[k].w;
+    for (int q = 0; q < NPOS; ++q) {
+        const int pos = tid + q * NT;
+        const int gg = pos / (N / 4), c4 = pos % (N / 4);
+        if (gg < live) {
+            float2* z = s + gg * PL + pad_idx(4 * c4);                    // (4 c4 + i and 4 c4 share their padding block for i < 4)
+            z[0] = make_float2(va[q].x, vb[q].x); z[1] = make_float2(va[q].y, vb[q].y);
+            z[2] = make_float2(va[q].z, vb[q].z); z[3] = make_float2(va[q].w, vb[q].w);
         }
     }
     __syncthreads();
     fft_lds<N, -1>(s + g * PL, t, tws);
 
-    // (Wc is a power of two: shifts, not the ~20-instruction expansion of a division by a run-time value, twice per item)
+    // Hermitian split of Z = FFT(a + i*b) into the two rows' packed half spectra: a thread takes bins k, k+1 of BOTH rows (the four
+    // elements Z[k], Z[k+1], Z[N-k], Z[N-k-1] are read once) and stores 16 bytes to each.  Wc is a power of two: shifts, not the
+    // ~20-instruction expansion of a division by a run-time value.
     const int half = Wc / 2, hs = 31 - __builtin_clz(half);
-    for (int it = tid; it < G * 2 * half; it += NT) {
-        const int gg = it >> (hs + 1), rem = it & (2 * half - 1);
-        const int row = rem >> hs, k = (rem & (half - 1)) * 2;
-        if (pair0 + gg >= npairs) continue;
+    float2* const obase = mid + pair0 * 2 * Wc;
+    for (int it = tid; it < G * half; it += NT) {
+        const int gg = it >> hs, k = (it & (half - 1)) * 2;
+        if (gg >= live) continue;
         const float2* z = s + gg * PL;
-        const float2 r0 = split_rows<N>(z, k, row), r1 = split_rows<N>(z, k + 1, row);
-        float4* dst = reinterpret_cast<float4*>(mid + ((pair0 + gg) * 2 + row) * Wc + k);
-        *dst = make_float4(r0.x, r0.y, r1.x, r1.y);
+        const float2 zk1 = z[pad_idx(k + 1)], zn1 = z[pad_idx(N - k - 1)];
+        float2 a0, b0;
+        if (k == 0) {
+            const float2 z0 = z[pad_idx(0)], zh = z[pad_idx(N / 2)];      // DC in .x and Nyquist in .y of the packed column
+            a0 = make_float2(z0.x, zh.x); b0 = make_float2(z0.y, zh.y);
+        } else {
+            const float2 zk = z[pad_idx(k)], zn = z[pad_idx(N - k)];
+            a0 = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)); b0 = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+        const float2 a1 = make_float2(0.5f * (zk1.x + zn1.x), 0.5f * (zk1.y - zn1.y)), b1 = make_float2(0.5f * (zk1.y + zn1.y), -0.5f * (zk1.x - zn1.x));
+        float2* dst = obase + (gg * 2 * Wc + k);                              // (uniform base + 32-bit lane offset)
+        *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a0.y, a1.x, a1.y);
+        *reinterpret_cast<float4*>(dst + Wc) = make_float4(b0.x, b0.y, b1.x, b1.y);
     }
 }
 
@@ -322,22 +322,23 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     constexpr int NIT = G * (N / 4) / NT;                       // = 2 when NT = G*N/8
     static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of items per thread");
     float4 av[NIT], bv[NIT];
+    const int live = npairs - pair0 < G ? (int)(npairs - pair0) : G;      // row pairs of this workgroup that exist (uniform)
+    const float2* const ibase = mid + pair0 * 2 * Wc;                     // (uniform base + 32-bit lane offsets; masked lanes read element 0)
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
         const int it = tid + q * NT;
         const int gg = it / (N / 4), k = (it % (N / 4)) * 2;
-        const bool ok = (pair0 + gg < npairs) && k < Wc;
-        const long pr = (pair0 + gg < npairs) ? pair0 + gg : npairs - 1;
-        const float2* rowA = mid + (pr * 2) * Wc + (k < Wc ? k : 0);
-        av[q] = ld_stream(reinterpret_cast<const float4*>(rowA));
-        bv[q] = ld_stream(reinterpret_cast<const float4*>(rowA + Wc));
+        const bool ok = gg < live && k < Wc;
+        const int off = ok ? gg * 2 * Wc + k : 0;
+        av[q] = ld_stream(reinterpret_cast<const float4*>(ibase + off));
+        bv[q] = ld_stream(reinterpret_cast<const float4*>(ibase + off + Wc));
         if (!ok) { av[q] = make_float4(0.f, 0.f, 0.f, 0.f); bv[q] = av[q]; }
     }
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
         const int it = tid + q * NT;
         const int gg = it / (N / 4), k = (it % (N / 4)) * 2;
-        if (pair0 + gg >= npairs) continue;
+        if (gg >= live) continue;
         float2* z = s + gg * PL;
         const float4 a = av[q], b = bv[q];
         if (k == 0) {
@@ -353,16 +354,19 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     __syncthreads();
     fft_lds<N, +1>(s + g * PL, t, tws);
 
-    constexpr int NV = G * 2 * N / 4;
-    float4* dst = reinterpret_cast<float4*>(out + pair0 * 2 * N);
-    for (int v = tid; v < NV; v += NT) {
-        const int e = v * 4;
-        const int gg = e / (2 * N), o = e % (2 * N);
-        const int row = o / N, n0 = o % N;
-        if (pair0 + gg < npairs) {
-            const float* zs = reinterpret_cast<const float*>(s + gg * PL) + row;
-            st_stream(&dst[v], make_float4(zs[2 * pad_idx(n0)] * scale, zs[2 * pad_idx(n0 + 1)] * scale,
-                                           zs[2 * pad_idx(n0 + 2)] * scale, zs[2 * pad_idx(n0 + 3)] * scale));     // (the images are not read again)
+    // four consecutive complex elements per lane (read once, adjacent in the padded layout): their real parts are 16 bytes of row A, their
+    // imaginary parts 16 bytes of row B
+    constexpr int NQ = G * (N / 4) / NT;
+    float* const orow = out + pair0 * 2 * N;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + q * NT;
+        const int gg = idx / (N / 4), n = (idx % (N / 4)) * 4;
+        if (gg < live) {
+            const float2* z = s + gg * PL + pad_idx(n);
+            const float2 z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3];
+            st_stream(reinterpret_cast<float4*>(orow + (gg * 2) * N + n), make_float4(z0.x * scale, z1.x * scale, z2.x * scale, z3.x * scale));     // (the images are not read again)
+            st_stream(reinterpret_cast<float4*>(orow + (gg * 2 + 1) * N + n), make_float4(z0.y * scale, z1.y * scale, z2.y * scale, z3.y * scale));
         }
     }
 }
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int it = tid + k * NT;
-        val[k] = ld_stream(reinterpret_cast<const float4*>(src + (long)(it / (CW / 2)) * Wc + 2 * (it % (CW / 2))));     // (mid dies here)
+        val[k] = ld_stream(reinterpret_cast<const float4*>(src + ((it / (CW / 2)) * Wc + 2 * (it % (CW / 2)))));     // (mid dies here; 32-bit lane offset)
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -428,10 +432,10 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
         if (col == 0) {
             // column 0 carries DC + i*Nyquist of the row pass: split by Hermitian symmetry along x
             const float2 zn = s[pad_idx((N - si) % N)];
-            dst[(long)i * Nyrs] = make_float2(0.5f * (z.x + zn.x), 0.5f * (z.y - zn.y));
-            dst[(long)i * Nyrs + Wc] = make_float2(0.5f * (z.y + zn.y), -0.5f * (z.x - zn.x));
+            dst[i * Nyrs] = make_float2(0.5f * (z.x + zn.x), 0.5f * (z.y - zn.y));
+            dst[i * Nyrs + Wc] = make_float2(0.5f * (z.y + zn.y), -0.5f * (z.x - zn.x));
         } else {
-            dst[(long)i * Nyrs + col] = z;
+            dst[i * Nyrs + col] = z;
         }
     }
 }

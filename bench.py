@@ -56,7 +56,7 @@ PMC_FAMILY = {"contract": ["contract_mfma_kernel", "contract_fast_kernel", "cont
 def pmc_traffic(variant, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note; tools/pmc.py).  None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_cfg3{variant}.json")
+    path = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_cfg3{variant}.json")
     if not os.path.exists(path):
         return None
     d = json.load(open(path))

@@ -8,9 +8,9 @@ R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/prof_$variant
 export TMPDIR=${TMPDIR:-/tmp}; cd "$TMPDIR"
 rm -rf $O && mkdir -p $O
 extra=""; [ "$variant" = "p1" ] && extra="--steps 5 --warmup 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --variant $variant --no-cpu-baseline --no-variants $extra > $O/bench_under_rocprof.json 2> $O/stats.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --variant $variant --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 $R/bench.py --variant $variant --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-variants > $O/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --variant $variant --no-cpu-baseline --no-variants --no-dp-probe $extra > $O/bench_under_rocprof.json 2> $O/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --variant $variant --steps 3 --warmup 1 --steady-steps 0 --no-dp-probe --no-cpu-baseline --no-roofline --no-variants > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 $R/bench.py --variant $variant --steps 3 --warmup 1 --steady-steps 0 --no-dp-probe --no-cpu-baseline --no-roofline --no-variants > $O/write.log 2>&1
 cd $R
 mkdir -p profiles gpurun_out/profiles_new
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) profiles/${tag}_kernel_stats_cfg3$variant.csv

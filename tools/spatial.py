@@ -24,9 +24,13 @@ print({k: round(v["ms"] * 1e3, 1) for k, v in pr.items() if v["launches"]})
 ctx.prof_enable(False)
 def step():
     h = ctx.conv_spatial(x, c, b); o = ctx.conv_spatial(h, f, p); ctx.backprop_spatial(x, o, h, c, b, f, p, mom, grads, 0.2, 0.9)
-for _ in range(3): step()
-ctx.sync(); t0 = time.perf_counter()
-for _ in range(20): step()
-ctx.sync(); print(f"step {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms (flags {os.environ.get('FLAGS', '')})")
+hb, ob = ctx.empty(B, dM, N, N), ctx.empty(B, dD, N, N)
+def fused():
+    ctx.step_spatial(x, c, b, f, p, mom, grads, 0.2, 0.9, hin=hb, out=ob)
+for name, fn in (("separate calls", step), ("fused step (aefft_step_spatial)", fused)):
+    for _ in range(3): fn()
+    ctx.sync(); t0 = time.perf_counter()
+    for _ in range(20): fn()
+    ctx.sync(); print(f"step, {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms (flags {os.environ.get('FLAGS', '')})")
 flops_conv = 2.0 * B * dM * dD * Nk * Nk * N * N
 print(f"conv flops {flops_conv/1e9:.2f} GF each")
