@@ -305,8 +305,13 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     }
 }
 
-// row pass, inverse: packed half spectra (Wc columns, the rest zero) -> two real rows
-template <int N>
+// row pass, inverse: packed half spectra (Wc columns, the rest zero) -> two real rows.
+// SPARSE (Wc <= N/16: the training step's reconstruction, whose spectrum lives on the coarsest grid -- 16 of 256 columns at cfg3): of the N
+// inputs of a row pair's transform only Z[0 .. Wc), Z[N/2] and Z(N - Wc .. N) are non-zero, i.e. butterfly t of the FIRST radix-8 pass
+// (inputs t + tt*N/8) has ONE non-zero input -- tt = 0 for t < Wc, tt = 7 for t > N/8 - Wc -- plus the Nyquist element (tt = 4) at t = 0.  The
+// thread loads that element itself and forms the pass's outputs  X[u] = a0 + (-1)^u a4 + a7 conj(w8)^u  in registers: no staging of the tile
+// through LDS, no first-pass LDS reads, a third of the first pass's arithmetic; the passes at strides 8 and 64 follow unchanged.
+template <int N, bool SPARSE>
 __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* __restrict__ mid, float* __restrict__ out,
                                                                    long npairs, int Wc, float scale)
 {
@@ -318,6 +323,41 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     FftTw<N, +1> tws;
     tws.load(t);
     const long pair0 = (long)blockIdx.x * G;
+    if constexpr (SPARSE) {
+        static_assert(N >= 128, "sparse head: three radix-8 passes or more");
+        const int live = npairs - pair0 < G ? (int)(npairs - pair0) : G;
+        const float2* const ibase = mid + pair0 * 2 * Wc;
+        // this butterfly's non-zero input: column k of the pair's two packed rows A, B
+        const bool lo = t < Wc, hi = t > T - Wc;                              // (disjoint: Wc <= T/2)
+        const int k = lo ? t : (hi ? T - t : 0);
+        const bool ok = g < live && (lo || hi);
+        const int off = ok ? g * 2 * Wc + k : 0;
+        float2 A = ibase[off], B = ibase[off + Wc];
+        if (!ok) { A = make_float2(0.f, 0.f); B = A; }
+        const float2 zz = make_float2(0.f, 0.f);
+        // t = 0: DC of both rows in .x, Nyquist in .y of the packed column (imaginary parts ignored)
+        const float2 a0 = lo ? (t == 0 ? make_float2(A.x, B.x) : make_float2(A.x - B.y, A.y + B.x)) : zz;      // Z[t]
+        const float2 a4 = t == 0 ? make_float2(A.y, B.y) : zz;                                                 // Z[N/2]
+        const float2 a7 = hi ? make_float2(A.x + B.y, -A.y + B.x) : zz;                                        // Z[N - k] = conj(A) + i conj(B)
+        // X[u] = a0 + (-1)^u a4 + a7 * exp(-i pi u / 4)   (inverse transform: w8 = exp(+i pi/4), input 7 carries w8^(7u) = conj(w8)^u)
+        const float c = 0.70710678118654752440f;
+        const float2 e = cadd(a0, a4), o = csub(a0, a4);
+        const float2 r1 = make_float2(c * (a7.x + a7.y), c * (a7.y - a7.x));   // a7 * exp(-i pi/4)
+        const float2 r2 = make_float2(a7.y, -a7.x);                            // a7 * (-i)
+        const float2 r3 = make_float2(c * (a7.y - a7.x), -c * (a7.x + a7.y));  // a7 * exp(-3 i pi/4)
+        float2 x[8] = {cadd(e, a7), cadd(o, r1), cadd(e, r2), cadd(o, r3), csub(e, a7), csub(o, r1), csub(e, r2), csub(o, r3)};
+        // twiddles W_N^(t u) of the first pass (fft_pass: p = t, S = 1), then the outputs to their Stockham slots 8 t + u
+        const float2 w1 = tws.w[0];
+        const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+        x[1] = cmul(x[1], w1); x[2] = cmul(x[2], w2); x[3] = cmul(x[3], w3); x[4] = cmul(x[4], w4);
+        x[5] = cmul(x[5], w5); x[6] = cmul(x[6], w6); x[7] = cmul(x[7], w7);
+        float2* z = s + g * PL;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[pad_idx(8 * t + u)] = x[u];
+        pass_sync<N>();
+        Passes<N, 8, 1, +1>::run(z, t, tws);
+    } else {
     // Z[k] = A[k] + i*B[k], Z[N-k] = conj(A[k]) + i*conj(B[k]); k handled in pairs (k, k+1), k even < N/2
     constexpr int NIT = G * (N / 4) / NT;                       // = 2 when NT = G*N/8
     static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of items per thread");
@@ -353,11 +393,13 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void c2r_rows_kernel(const float2* _
     }
     __syncthreads();
     fft_lds<N, +1>(s + g * PL, t, tws);
+    }
 
     // four consecutive complex elements per lane (read once, adjacent in the padded layout): their real parts are 16 bytes of row A, their
     // imaginary parts 16 bytes of row B
     constexpr int NQ = G * (N / 4) / NT;
     float* const orow = out + pair0 * 2 * N;
+    const int live = npairs - pair0 < G ? (int)(npairs - pair0) : G;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int idx = tid + q * NT;
@@ -661,10 +703,18 @@ template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, l
 {
     using Cfg = RowCfg<N>;
     const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL);
-    hipError_t e = allow_lds(c2r_rows_kernel<N>, lds);
-    if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
-    c2r_rows_kernel<N><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(mid, out, npairs, Wc, scale);
+    if constexpr (N >= 128) {
+        if (Wc <= N / 16) {                          // few non-zero columns (the reconstruction of a pooled network): sparse first pass
+            hipError_t e = allow_lds(c2r_rows_kernel<N, true>, lds);
+            if (e != hipSuccess) return e;
+            c2r_rows_kernel<N, true><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(mid, out, npairs, Wc, scale);
+            return hipGetLastError();
+        }
+    }
+    hipError_t e = allow_lds(c2r_rows_kernel<N, false>, lds);
+    if (e != hipSuccess) return e;
+    c2r_rows_kernel<N, false><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(mid, out, npairs, Wc, scale);
     return hipGetLastError();
 }
 template <int N, int CW> static hipError_t run_fwd_cols(const float2* mid, float2* out, long planes, int Wc, int Nxs, hipStream_t st, hipEvent_t done)

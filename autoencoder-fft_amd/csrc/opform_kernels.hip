@@ -23,6 +23,8 @@ namespace aefft {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+// (complex multiply-accumulates as two v_pk_fma_f32 with op_sel / neg modifiers -- no swizzle instructions, bit-identical -- were measured in round 4:
+// the tail launch 28 -> 34 us, the step 0.160 -> 0.166 ms; these kernels wait on memory round trips, not on VALU issue slots: DESIGN.md section 6)
 __device__ __forceinline__ void cfma2(float2& acc, float2 a, float2 b) { acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x); acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y); }
 __device__ __forceinline__ void cfmac(float2& acc, float2 a, float2 b) { acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(a.y, b.y, acc.x); acc.y = fmaf(a.y, b.x, acc.y); acc.y = fmaf(-a.x, b.y, acc.y); }   // += a * conj(b)
 // element `e` of a base with a 32-bit BYTE offset: with a uniform base the load takes the scalar-base + 32-bit lane offset form (callers

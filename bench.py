@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--preheat", type=int, default=0, help="EXTRA untimed steps in front of the W warm-up steps (reported as preheat_steps; 0 = the contract's protocol)")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the second timed region behind the headline one (reported as steady_state; 0 = skip)")
+    ap.add_argument("--force-rccl-step", action="store_true", help="N = 1 with --rccl: run the timed loop through libaefft_dp.so as N > 1 does (rehearsal of the multi-GPU host path on one GPU)")
     ap.add_argument("--torch-dist-loop", action="store_true", help="N > 1: all-reduce through torch.distributed (dp.DataParallelStep) instead of libaefft_dp.so")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (weak scaling)")
     ap.add_argument("--variant", choices=["p2", "p1"], default="p2")
@@ -345,7 +346,7 @@ def main():
     # step_grad -> ncclAllReduce(SUM) on the library's stream -> step_apply(1/world) in ONE C call: no Python, no torch.distributed inside
     # the step (torch.distributed only carries the ncclUniqueId, the barriers around the timed region and the max over ranks).
     rstep = None
-    if world > 1 and not a.torch_dist_loop:
+    if (world > 1 or (a.force_rccl_step and dist is not None)) and not a.torch_dist_loop:
         def bcast(idbuf):
             t = idbuf.to(dev)
             dist.broadcast(t, 0)
