@@ -1069,6 +1069,8 @@ struct aefft_net {
     // post-update MSE still reads this step's operators
     bool op_chain = false;     // the last step_grad ran in chain mode: operators in set op_fwd, activation buffers NOT refreshed (act_stale)
     bool act_stale = false;    // the activation buffers do not hold the last forward's frames (ensure_frames expands them from the operators)
+    bool upd_after_fwd = false; // aefft_net_step_apply has changed the weights since the step's forward: a layer export forms a skipped hidden layer with
+                               // the encoder of THAT forward, recovered as w + D (the momentum buffer holds the step that was applied)
     bool chain_valid = false;  // set op_set holds the operators of the CURRENT weights
     int op_set = 0, op_fwd = 0;
     float2* Wp = nullptr;      // [Pc][packE] bin-major copy of the kernel spectra the coarsest-grid chain items read (kspec_packed_kernel)
@@ -1254,6 +1256,7 @@ extern "C" int aefft_net_pair_shape(aefft_net* n, int l, int* dD, int* dM, int* 
 extern "C" int aefft_net_reset_momentum(aefft_net* n)
 {
     if (!n) return AEFFT_EINVAL;
+    n->upd_after_fwd = false;          // (w + D no longer is the previous weight)
     aefft_ctx* ctx = n->ctx;
     for (auto& q : n->pr) {
         const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
@@ -1268,6 +1271,7 @@ extern "C" int aefft_net_reset_momentum(aefft_net* n)
 extern "C" int aefft_net_set_pair(aefft_net* n, int l, const float* c_h, const float* b_h, const float* f_h, const float* p_h)
 {
     if (!n || l < 0 || l >= n->L || !c_h || !b_h || !f_h || !p_h) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_set_pair: bad argument");
+    n->upd_after_fwd = false;
     aefft_ctx* ctx = n->ctx;
     Pair& q = n->pr[l];
     const size_t nk = (size_t)q.dM * q.dD * q.Nk * q.Nl;
@@ -1338,6 +1342,7 @@ extern "C" int aefft_net_store_spectra(aefft_net* n, int l, float* C_h, float* F
 extern "C" int aefft_net_load_spectra(aefft_net* n, int l, const float* C_h, const float* b_h, const float* F_h, const float* p_h)
 {
     if (!n || l < 0 || l >= n->L || !C_h || !b_h || !F_h || !p_h) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_load_spectra: bad argument");
+    n->upd_after_fwd = false;
     aefft_ctx* ctx = n->ctx;
     Pair& q = n->pr[l];
     const size_t W = (size_t)q.dM * q.dD * q.P * sizeof(float2);
@@ -1576,6 +1581,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     ctx->biasColP1 = op ? (int)OPC : 0;        // conv_k biases: the affine column only
     RET_IF(join_recon(ctx));
     n->xx_done = false; n->ox_done = 0;
+    n->upd_after_fwd = false;
     // the whole network on the basis frames in one launch (chain_kernel): hidden layers not materialised, decoder outputs on the
     // coarsest grid's support, operators in their own buffers
     const bool chain_plan = op && lazy && n->Wp && (n->compact || L == 1) && chain_switches_ok();
@@ -1823,8 +1829,26 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
             c = q.dM; S = q.H;
             if (out_d && q.H_stale) {          // hidden layer skipped by the training step's forward: form it now (fft_backproplib.cu:1347)
                 Pair& qm = n->pr[(layer - 1) / 2];
-                RET_IF(ensure_spectra(n, qm));
-                RET_IF(do_conv(n->ctx, qm.X, qm.C, qm.b, qm.H, n->B, qm.dM, qm.dD, qm.Nx, qm.Ny));
+                if (n->upd_after_fwd && n->op_chain) {
+                    // chain form after aefft_net_step_apply: X_l is the step's own (expanded from its operators), so the hidden layer must
+                    // come from the step's encoder too, not from the updated one.  The update was w <- w - D with D left in the momentum
+                    // buffer: c_old = c + Dc, b_old = b + Db (to one rounding of the subtraction), its spectrum into the pair's planar C
+                    // buffer -- which this form keeps stale anyway (spectra_valid stays false: rebuilt from the current weights on demand).
+                    const size_t nk = (size_t)qm.dM * qm.dD * qm.Nk * qm.Nl;
+                    void *tmp, *real = nullptr;
+                    RET_IF(ws_get(ctx, WS_TMP, sizeof(float) * (nk + qm.dM), &tmp));
+                    float* c_old = (float*)tmp; float* b_old = c_old + nk;
+                    hipError_t e = launch_vec_add(c_old, qm.c, qm.Dc, (long)nk, ctx->cur);
+                    if (e == hipSuccess) e = launch_vec_add(b_old, qm.b, qm.Db, qm.dM, ctx->cur);
+                    if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "get_layer: previous encoder", e);
+                    if (!pruned_supported(qm.Nk, qm.Nl, qm.Nx, qm.Ny)) real = n->real;
+                    qm.spectra_valid = false;
+                    RET_IF(do_pad_r2c(ctx, c_old, qm.C, (float*)real, (long)qm.dM * qm.dD, qm.Nx, qm.Ny, qm.Nk, qm.Nl));
+                    RET_IF(do_conv(n->ctx, qm.X, qm.C, b_old, qm.H, n->B, qm.dM, qm.dD, qm.Nx, qm.Ny));
+                } else {
+                    RET_IF(ensure_spectra(n, qm));
+                    RET_IF(do_conv(n->ctx, qm.X, qm.C, qm.b, qm.H, n->B, qm.dM, qm.dD, qm.Nx, qm.Ny));
+                }
                 qm.H_stale = false;
             }
         }
@@ -1926,6 +1950,7 @@ static int pair_apply(aefft_net* n, Pair& q, float del, int maxdiff, int sym, fl
 extern "C" int aefft_net_train_pair(aefft_net* n, int l, int n_iter, float del0, int maxdiff, int sym, float* mse_h)
 {
     if (!n || l < 0 || l >= n->L || n_iter < 0) return fail(n ? n->ctx : nullptr, AEFFT_EINVAL, "aefft_net_train_pair: bad argument");
+    n->upd_after_fwd = false;
     aefft_ctx* ctx = n->ctx;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_train_pair: run aefft_net_forward first (the burst trains on its layers)");
     RET_IF(mse_flush(n));
@@ -2548,6 +2573,7 @@ extern "C" int aefft_net_step_apply(aefft_net* n, float del0, int maxdiff, int s
     const float del = 0.1f * del0;
     RET_IF(apply_grouped(n, del, maxdiff, sym, grad_scale, mse_d));
     n->have_grad = false;
+    n->upd_after_fwd = true;
     RET_IF(join_recon(ctx));
     return mark_step_point(n);
 }

@@ -245,6 +245,7 @@ struct UpdateArgs {
     float* zero;                          // optional: one float set to 0 (the pair's MSE accumulator, saves a memset launch)
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_vec_add(float* out, const float* a, const float* b, long n, hipStream_t st);      // out = a + b
 struct UpdateGroup { UpdateArgs a[8]; int n; int start[9]; };
 hipError_t launch_update_group(UpdateGroup& g, hipStream_t st);                                       // up to 8 pairs, one launch                                      // fft.cu:605 / 657
 size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl);      // floats of launch_gradient_diff's workspace (chunk partial sums)

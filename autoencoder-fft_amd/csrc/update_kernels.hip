@@ -91,6 +91,19 @@ hipError_t launch_update_group(UpdateGroup& g, hipStream_t st)
     return hipGetLastError();
 }
 
+// out = a + b (the weights of the step before the last update: w_old = w + D, the momentum buffer holds the step that was applied)
+__global__ __launch_bounds__(256) void vec_add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+hipError_t launch_vec_add(float* out, const float* a, const float* b, long n, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    vec_add_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(out, a, b, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
 {
     const int n = a.dM * a.dD * a.Nk * a.Nl;

@@ -225,8 +225,10 @@ int aefft_net_forward(aefft_net* net, const float* frames_d, float* recon_d);
  *   OPERATOR        the per-frame forward of the frames of the last step_grad is re-run with the CURRENT weights: the caller's frame buffer
  *                   must still hold them, and after aefft_net_step_apply the layers are those of the updated weights;
  *   PER_FRAME       the spectra of the step's forward as stored.
- * In every form a HIDDEN layer (even index <= 2L) that the training step did not materialise is formed on request from the pair's input
- * of the step and the pair's CURRENT encoder. */
+ * A HIDDEN layer (even index <= 2L) that the training step did not materialise is formed on request from the pair's input of the step and
+ * the encoder of THAT step: in the OPERATOR_CHAIN form after aefft_net_step_apply the pre-update encoder is recovered as w + D (the update was
+ * w <- w - D and D stays in the momentum buffer: exact to one rounding), so every layer of one export belongs to the same weight set; in
+ * the other two forms from the pair's CURRENT encoder (PER_FRAME before step_apply, OPERATOR as described above). */
 int aefft_net_get_layer(aefft_net* net, int layer, float* out_d, int* ch, int* nx, int* ny);
 
 /* fft_l = 1 in one call: EVERY layer 0..4L of the last forward, coordinate space, packed into out_d at the

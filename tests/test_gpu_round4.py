@@ -246,3 +246,50 @@ def test_pooling_by_scales_that_are_not_powers_of_two(ctx, N, s):
     assert relerr(host(ctx.r2c_pool(ctx.dev(x), s)), down) < 1e-5
     y = ctx.unpool_c2r(ctx.dev(down), ny, -s, 1.0 / (N * N))
     assert relerr(host(y), R.fft_inv(up, N, N)) < 2e-5
+
+
+def test_layer_exports_after_step_apply_are_one_consistent_forward(ctx, flags):
+    """in the chain form a layer export after aefft_net_step_grad + aefft_net_step_apply mixed the step's own X_l / O_l with hidden
+    layers recomputed from the UPDATED encoder.  Now the hidden layers come from the step's encoder too (w + D: the applied step stays in the
+    momentum buffer): every one of the 4L+1 layers == the fft_l = 1 export of a fresh net holding the ORIGINAL weights (fft_backproplib.cu:1347,
+    1357,1361), hidden layers included, with momentum from an earlier step in play."""
+    flags()
+    rng = np.random.default_rng(404)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6, 5], 5, 2, 3
+    L = len(maps)
+    ws, dD = [], D
+    for dM in maps:
+        q32 = lambda a: a.astype(np.float32)
+        ws.append((q32(rng.uniform(-1, 1, (dM, dD, Nk, Nk))), q32(rng.uniform(-1, 1, dM)), q32(rng.uniform(-1, 1, (dD, dM, Nk, Nk))), q32(rng.uniform(-1, 1, dD)))); dD = dM
+    x0 = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    x1 = ctx.dev(np.floor(rng.uniform(0, 256, (B, D, N, N))))
+    net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(ws):
+        net.set_pair(l, *w)
+    assert net.step_form() == "operator_chain"
+    net.step_grad(x0, None); net.step_apply(0.2)                     # a first step: momentum is non-zero afterwards
+    before = [net.get_pair(l) for l in range(L)]                     # the weights step 2's forward sees
+    net.step_grad(x1, None); net.step_apply(0.2)
+    got = [host(t).copy() for t in net.get_layers()]
+    after = [net.get_pair(l) for l in range(L)]
+    assert np.abs(after[0][0] - before[0][0]).max() > 1e-4           # the update happened
+    fresh = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(before):
+        fresh.set_pair(l, *w)
+    fresh.forward(x1, None)
+    ref = [host(t) for t in fresh.get_layers()]
+    for l in range(4 * L + 1):
+        assert relerr(got[l], ref[l]) < 5e-5, (l, relerr(got[l], ref[l]))
+    # ... and the next step is not disturbed by the export (the planar C buffer it borrowed is marked stale)
+    mse = ctx.empty(L)
+    net.step_grad(x0, None); net.step_apply(0.2, 0, 0, 1.0, mse)
+    w_exp = [net.get_pair(l) for l in range(L)]
+    net2 = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+    for l, w in enumerate(ws):
+        net2.set_pair(l, *w)
+    for xx in (x0, x1, x0):
+        net2.step_grad(xx, None); net2.step_apply(0.2)
+    for a, b in zip(w_exp, [net2.get_pair(l) for l in range(L)]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    net.close(); fresh.close(); net2.close()
