@@ -22,6 +22,7 @@ namespace aefft {
 // row k) owns the NK outputs g[m][a][k][0..NK): per (d1, k2) it reads one weight row (NK floats) and one Q row (T floats)
 // for NK*NK FMAs (a 1-D valid correlation in registers), i.e. ~0.5 LDS reads per FMA instead of 2.
 // Blocks of a problem: [0, dD*mt) -> g_c, [dD*mt, 2*dD*mt) -> g_f, mt = ceil(dM/TM).
+constexpr int WG_DB = 32;            // inner channels staged per block (a multiple of the 8 slices)
 template <int NK>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
 {
@@ -41,97 +42,105 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
     const bool isf = blk >= dD * mt;
     if (isf) blk -= dD * mt;
     const int a = blk / mt, m0 = (blk - a * mt) * TM;
+    // The inner channels d1 go through LDS in blocks of WG_DB: a pair with 64 inner channels (cfg5's 64 -> 128) would otherwise need 64 KB per
+    // workgroup, and the launch's LDS size -- the largest pair's -- applies to EVERY workgroup of the grouped launch: 2 per CU instead of 4.
+    // Per slice the channels are still visited in ascending order: the sums are those of the single-block form, bit for bit.
+    const int DBmax = dD < WG_DB ? dD : WG_DB;
     float* Qs = sh;
-    float* ws = sh + dD * TT;
-    float* red = ws + dD * TM * KK;
-    // staging in batches of 8 independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
-    // one memory round trip per element otherwise)
-    auto wload = [&](int t) {
-        t = min(t, dD * TM * KK - 1);
-        const int d1 = t / (TM * KK), rem = t - d1 * (TM * KK);
-        const int m2 = min(m0 + rem / KK, dM - 1), r = rem % KK;
-        return isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
-    };
-    // the first 24 loads per thread of the weight slab go out BEFORE the Q loads: both are in flight in the same round trip
-    float wv[24];
-#pragma unroll
-    for (int u = 0; u < 24; ++u) {
-        if (u * 256 >= dD * TM * KK) break;                          // uniform
-        wv[u] = wload(u * 256 + (int)threadIdx.x);
-    }
-    const int nq = q.nq;
-    if (nq <= 1) {
-        for (int t0 = 0; t0 < dD * TT; t0 += 256 * 12) {
-            float v[12];
-#pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                if (t0 + u * 256 >= dD * TT) break;                       // uniform
-                const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
-                const int d1 = t / TT, r = t - d1 * TT;
-                v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
-            }
-#pragma unroll
-            for (int u = 0; u < 12; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = v[u]; }
-        }
-    } else {
-        // the producer left nq row-chunk partial sums per plane ([plane][chunk][tap]): added here in chunk order, 4 elements x 4
-        // chunks of independent loads per batch
-        for (int t0 = 0; t0 < dD * TT; t0 += 256 * 4) {
-            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < nq; c0 += 4) {
-                float v[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = min(t0 + u * 256 + (int)threadIdx.x, dD * TT - 1);
-                    const int d1 = t / TT, r = t - d1 * TT;
-                    const long pl = isf ? (long)a * dD + d1 : (long)d1 * dD + a;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[u][c] = q.Q[(pl * nq + min(c0 + c, nq - 1)) * TT + r];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) if (c0 + c < nq) acc4[u] += v[u][c];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TT) Qs[t] = acc4[u]; }
-        }
-    }
-    // the rest of the weight slab (the innermost pair's is 37 loads per thread: one more round trip, not four)
-#pragma unroll
-    for (int u = 0; u < 24; ++u) { const int t = u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = wv[u]; }
-    for (int t0 = 256 * 24; t0 < dD * TM * KK; t0 += 256 * 24) {
-        float v[24];
-#pragma unroll
-        for (int u = 0; u < 24; ++u) {
-            if (t0 + u * 256 >= dD * TM * KK) break;                 // uniform: whole load instructions are skipped
-            v[u] = wload(t0 + u * 256 + (int)threadIdx.x);
-        }
-#pragma unroll
-        for (int u = 0; u < 24; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < dD * TM * KK) ws[t] = v[u]; }
-    }
-    __syncthreads();
+    float* ws = sh + DBmax * TT;
+    float* red = ws + DBmax * TM * KK;
     const int s = threadIdx.x / (TM * NK), rem = threadIdx.x - s * (TM * NK);
     const int ml = rem / NK, k = rem - ml * NK;
     const int m = m0 + ml;
     float acc[NK];
 #pragma unroll
     for (int l = 0; l < NK; ++l) acc[l] = 0.f;
-    if (s < SL && m < dM) {
-        for (int d1 = s; d1 < dD; d1 += SL) {
-            const float* wb = ws + (d1 * TM + ml) * KK;
-            const float* Qb = Qs + d1 * TT + k * T;
+    const int nq = q.nq;
+    for (int db = 0; db < dD; db += WG_DB) {
+        const int nb = dD - db < WG_DB ? dD - db : WG_DB;
+        if (db > 0) __syncthreads();                                  // the previous block's tiles have been consumed
+        // staging in batches of independent loads per thread (hipcc keeps load -> wait -> store order inside a rolled loop:
+        // one memory round trip per element otherwise)
+        auto wload = [&](int t) {
+            t = min(t, nb * TM * KK - 1);
+            const int d1 = db + t / (TM * KK), r2 = t % (TM * KK);
+            const int m2 = min(m0 + r2 / KK, dM - 1), r = r2 % KK;
+            return isf ? q.c[((long)m2 * dD + d1) * KK + r] : q.f[((long)d1 * dM + m2) * KK + r];
+        };
+        // the first 24 loads per thread of the weight slab go out BEFORE the Q loads: both are in flight in the same round trip
+        float wv[24];
 #pragma unroll
-            for (int k2 = 0; k2 < NK; ++k2) {
-                float w[NK], qr[T];
+        for (int u = 0; u < 24; ++u) {
+            if (u * 256 >= nb * TM * KK) break;                          // uniform
+            wv[u] = wload(u * 256 + (int)threadIdx.x);
+        }
+        if (nq <= 1) {
+            for (int t0 = 0; t0 < nb * TT; t0 += 256 * 12) {
+                float v[12];
 #pragma unroll
-                for (int l2 = 0; l2 < NK; ++l2) w[l2] = wb[k2 * NK + l2];
+                for (int u = 0; u < 12; ++u) {
+                    if (t0 + u * 256 >= nb * TT) break;                       // uniform
+                    const int t = min(t0 + u * 256 + (int)threadIdx.x, nb * TT - 1);
+                    const int d1 = db + t / TT, r = t % TT;
+                    v[u] = isf ? q.Q[((long)a * dD + d1) * TT + r] : q.Q[((long)d1 * dD + a) * TT + r];
+                }
 #pragma unroll
-                for (int t = 0; t < T; ++t) qr[t] = Qb[k2 * T + t];
+                for (int u = 0; u < 12; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < nb * TT) Qs[t] = v[u]; }
+            }
+        } else {
+            // the producer left nq row-chunk partial sums per plane ([plane][chunk][tap]): added here in chunk order, 4 elements x 4
+            // chunks of independent loads per batch
+            for (int t0 = 0; t0 < nb * TT; t0 += 256 * 4) {
+                float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c0 = 0; c0 < nq; c0 += 4) {
+                    float v[4][4];
 #pragma unroll
-                for (int l2 = 0; l2 < NK; ++l2)
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = min(t0 + u * 256 + (int)threadIdx.x, nb * TT - 1);
+                        const int d1 = db + t / TT, r = t % TT;
+                        const long pl = isf ? (long)a * dD + d1 : (long)d1 * dD + a;
 #pragma unroll
-                    for (int l = 0; l < NK; ++l) acc[l] = fmaf(w[l2], qr[l + l2], acc[l]);
+                        for (int c = 0; c < 4; ++c) v[u][c] = q.Q[(pl * nq + min(c0 + c, nq - 1)) * TT + r];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c0 + c < nq) acc4[u] += v[u][c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < nb * TT) Qs[t] = acc4[u]; }
+            }
+        }
+        // the rest of the weight slab (a 32-channel block is 19 loads per thread: inside the first batch)
+#pragma unroll
+        for (int u = 0; u < 24; ++u) { const int t = u * 256 + threadIdx.x; if (t < nb * TM * KK) ws[t] = wv[u]; }
+        for (int t0 = 256 * 24; t0 < nb * TM * KK; t0 += 256 * 24) {
+            float v[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) {
+                if (t0 + u * 256 >= nb * TM * KK) break;                 // uniform: whole load instructions are skipped
+                v[u] = wload(t0 + u * 256 + (int)threadIdx.x);
+            }
+#pragma unroll
+            for (int u = 0; u < 24; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < nb * TM * KK) ws[t] = v[u]; }
+        }
+        __syncthreads();
+        if (s < SL && m < dM) {
+            for (int d1 = s; d1 < nb; d1 += SL) {
+                const float* wb = ws + (d1 * TM + ml) * KK;
+                const float* Qb = Qs + d1 * TT + k * T;
+#pragma unroll
+                for (int k2 = 0; k2 < NK; ++k2) {
+                    float w[NK], qr[T];
+#pragma unroll
+                    for (int l2 = 0; l2 < NK; ++l2) w[l2] = wb[k2 * NK + l2];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) qr[t] = Qb[k2 * T + t];
+#pragma unroll
+                    for (int l2 = 0; l2 < NK; ++l2)
+#pragma unroll
+                        for (int l = 0; l < NK; ++l) acc[l] = fmaf(w[l2], qr[l + l2], acc[l]);
+                }
             }
         }
     }
@@ -160,7 +169,8 @@ hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
     for (int i = 0; i < g.n; ++i) {
         const WgradProb& q = g.q[i];
         g.start[i] = total; total += 2 * q.dD * ((q.dM + TM - 1) / TM);
-        lds = std::max(lds, sizeof(float) * ((size_t)q.dD * TT + (size_t)q.dD * TM * KK + 256 * Nk));
+        const size_t db = std::min(q.dD, WG_DB);
+        lds = std::max(lds, sizeof(float) * (db * TT + db * TM * KK + 256 * Nk));
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
