@@ -149,4 +149,29 @@ __device__ __forceinline__ void bias_grad_body(const float2* __restrict__ O, con
     if ((threadIdx.x & 63) == 0) db[m] = s * norm / den;
 }
 
+
+// Experiment builds only (tools/mkx.sh ... -DAEFFT_X_WGTIME=1, tools/wgtime.py): every workgroup of the instrumented kernels leaves the wall-clock time
+// (100 MHz) at which it started and ended in a debug buffer -- which workgroups of a grouped launch are the long pole.  Compiled out of the product.
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+static __device__ unsigned long long* g_wgtime = nullptr;   // [kernel slot][WGT_MAX][2], null = off; one copy per translation unit (no relocatable device code)
+static inline int wgtime_set_tu(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgtime), &q, sizeof q); }
+constexpr int WGT_MAX = 8192;
+struct WgTimer {
+    int slot; unsigned long long t0;
+    __device__ __forceinline__ WgTimer(int s) : slot(s), t0(wall_clock64()) {}
+    __device__ __forceinline__ ~WgTimer()
+    {
+        if (threadIdx.x == 0 && threadIdx.y == 0 && g_wgtime && blockIdx.x < WGT_MAX && blockIdx.y == 0) {
+            unsigned long long* p = g_wgtime + ((size_t)slot * WGT_MAX + blockIdx.x) * 2;
+            p[0] = t0; p[1] = wall_clock64();
+        }
+    }
+};
+#define AEFFT_WGTIME(slot) WgTimer wg_timer_(slot)
+// stage stamps inside a workgroup (thread 0, after the barrier that ends the stage): [5 slots][WGT_MAX][8] behind the start / end pairs
+#define AEFFT_WGSTAMP(slot, k) do { if (threadIdx.x == 0 && g_wgtime && blockIdx.x < WGT_MAX) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)(slot) * WGT_MAX + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define AEFFT_WGTIME(slot)
+#define AEFFT_WGSTAMP(slot, k) do { } while (0)
+#endif
 }  // namespace aefft

@@ -28,6 +28,7 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
 // opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
 // A[OPIN_COLS-1][d][t] + sum_{j<D0} A[j][d][t] * Xf[b][j][u(t)], A [OPIN_COLS][D0][Nxi*(Nyi/2+1)], Xf [B][D0][Nx0*(Ny0/2+1)]
 constexpr int OPIN_COLS = 4;
+constexpr int CH_MAXSTEPS = 12;       // steps of a per-bin chain item (chain_geometry)
 constexpr int CH_VMAX = 128;          // most rows of a matrix the packed-record kernels (chain, innermost-pair MSE) take
 struct OpIn { const float2* A; const float2* Xf; int D0, Nx0, Ny0; };
 hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi,
@@ -219,6 +220,8 @@ struct ChainArgs {
     const float2* Wp; int E;   // bin-major copy of every matrix a coarsest-grid bin needs (kspec_packed_kernel)
     int tile_start[9];         // (filled by launch_chain) first workgroup of the planar tiles of grid j
     int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
+    // (filled by launch_chain) the per-bin item's step list (chain_item_pipelined, opform_kernels.hip)
+    unsigned st_off[CH_MAXSTEPS], st_desc[CH_MAXSTEPS]; int st_n;
 };
 hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done = nullptr /* recorded by the dispatch itself */);
 // Wp[t][E]: per bin t of the coarsest grid the elements of C_0 .. C_{L-1}, F_{L-1} .. F_0 at the bins t maps to, from the taps

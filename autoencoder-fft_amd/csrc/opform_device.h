@@ -54,14 +54,17 @@ __device__ __forceinline__ float2 pk_cmul(float2 a, float2 b)
 // kspec_body) and every row then costs Nk complex multiplies: sum_k v_k e^{-2 pi i i kap_k / Nx}.  Stores are coalesced along e.
 constexpr int PACK_RG = 16;                     // (8: 25.2 us, 16: 22.9, 32: 29.5 for the merged launch at cfg3, with the 1024-workgroup target below)
 static inline int pack_yblocks(const PackArgs& g) { return (g.NyC / 2 + 1) * ((g.NxC + PACK_RG - 1) / PACK_RG); }
+// (LDS: `smem`, kspec_packed_lds(NK) bytes of the hosting kernel's dynamic region -- a static allocation would ADD to the dynamic size the
+// host launch asks for on behalf of its other workgroups: 52 KB instead of 26 KB per workgroup at cfg3)
+constexpr size_t kspec_packed_lds(int NK) { return sizeof(float2) * (size_t)(PACK_RG + 1) * (NK / 2 > 0 ? NK / 2 : 1) + sizeof(float) * 256 * (size_t)(NK * NK); }
 template <int NK>
-__device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int by)
+__device__ __forceinline__ void kspec_packed_body(const PackArgs& g, int bx, int by, void* smem)
 {
     constexpr int RG = PACK_RG, KK = NK * NK, H = NK / 2;
     static_assert(NK % 2 == 1, "symmetric tap offsets");
-    __shared__ float2 ph[RG + 1][H > 0 ? H : 1];                   // row phases of the RG rows, then the column's: offsets 1 .. H (the
-                                                                   // phase of a negative offset is the conjugate: kspec_body)
-    __shared__ float taps[256 * KK];                               // the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
+    float2 (*ph)[H > 0 ? H : 1] = reinterpret_cast<float2 (*)[H > 0 ? H : 1]>(smem);      // [RG + 1][H]: row phases of the RG rows, then the column's: offsets
+                                                                   // 1 .. H (the phase of a negative offset is the conjugate: kspec_body)
+    float* taps = reinterpret_cast<float*>(ph + RG + 1);           // [256 * KK]: the workgroup's 256 elements x Nk*Nk taps (coalesced copy)
     const PackSeg sd = g.seg[g.blk_seg[bx]];               // (uniform: a workgroup's elements belong to ONE tensor)
     const int l0 = g.blk_start[bx];                        // first element of the block inside the tensor
     const int nel = min(256, sd.n - l0);

@@ -30,6 +30,7 @@ __device__ __forceinline__ void cfmac(float2& acc, float2 a, float2 b) { acc.x =
 // element `e` of a base with a 32-bit BYTE offset: with a uniform base the load takes the scalar-base + 32-bit lane offset form (callers
 // guarantee e * 8 < 2^32)
 __device__ __forceinline__ float2 ld8(const float2* base, unsigned e) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + e * 8u); }
+__device__ __forceinline__ void st8(float2* base, unsigned e, float2 v) { *reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + e * 8u) = v; }
 
 // r M^ r^H for one row r of an operator, with M^ in its stored CENTRED form (msgrad_kernel): r~_3 = r_3 + sum_j r_j xbar_j, then
 // sum_{j,k<3} r_j M[j][k] conj(r_k) + B |r~_3|^2.  Mget(e): entry e = j*OPC + k of M^ at the row's bin.
@@ -87,8 +88,12 @@ hipError_t launch_basis_fill(float2* A0, int D0, long P0, hipStream_t st)
 // workgroups of pair 0, whose grid is the moments' grid, also store them).  Phase B: threads (bin, row a): U[a][.] = E~ M,
 // S[a][b] = sum_k U[a][k] conj(A~[b][k]) for every b.  All global loads of a workgroup are issued up front (one round trip).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
+#ifndef AEFFT_X_MSGRAD_W
+#define AEFFT_X_MSGRAD_W 1
+#endif
+__global__ __launch_bounds__(256, AEFFT_X_MSGRAD_W) void msgrad_kernel(const SgradGroup g)
 {
+    AEFFT_WGTIME(0);
     extern __shared__ float2 sh[];
     const int tid = threadIdx.x;
     int p = g.n - 1;                                                // pair n-1 owns the first workgroups (most dependent steps per workgroup), pair 0 the last
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
         for (int d = 0; d < 3; ++d) Kl[d * BT + bl] = K[d];
     }
     __syncthreads();
+    AEFFT_WGSTAMP(0, 0);
     for (int i = tid; i < 9 * BT; i += 256) {                       // slices -> one sum, in slice order (deterministic)
         const int e = i / BT, b2 = i - e * BT;
         float2 a = red[e * BT + b2];
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
         mom[i] = a;
     }
     __syncthreads();
+    AEFFT_WGSTAMP(0, 1);
     // the tiles take the place of the per-slice partial sums (held in registers since the first round trip)
 #pragma unroll
     for (int w = 0; w < 4; ++w) { const int idx = w * 256 + tid; if (idx < nA) { As[idx] = va[w]; Os[idx] = vo[w]; } }
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
         if (store_m && s0 + b2 < q.P) g.Mout[(size_t)e * P0 + (size_t)(s0 + b2)] = v;
     }
     __syncthreads();
+    AEFFT_WGSTAMP(0, 2);
     // ---- centre the affine columns: A~_1 = A_1 + sum_j A_j xbar_j (the same for O^) ----
     for (int a = ry; a < dD; a += RT) {
         float2 a3 = As[((OPC - 1) * dD + a) * BT + bl], o3 = Os[((OPC - 1) * dD + a) * BT + bl];
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(256) void msgrad_kernel(const SgradGroup g)
         As[((OPC - 1) * dD + a) * BT + bl] = a3; Os[((OPC - 1) * dD + a) * BT + bl] = o3;
     }
     __syncthreads();
+    AEFFT_WGSTAMP(0, 3);
     for (int a = ry; a < dD; a += RT) {
         float2 E[OPC], U[OPC];
 #pragma unroll
@@ -748,6 +757,9 @@ __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t,
 }
 
 // (the bodies take their workgroup index from blockIdx.x - g.base: the launch may host other work in front, tail_kernel)
+// LEAN: every pair of the launch is served by opmse_packed or opmse_gbody (launch_opmse_group checks) -- the bodies that read the planar
+// C' | F' are not instantiated: they need 103-121 registers against 62-78 for the rest, and a launch's allocation is its largest body's
+template <bool LEAN>
 __device__ __forceinline__ void opmse_dispatch(const OpMseGroup& g, float2* sh)
 {
     const int blk = (int)blockIdx.x - g.base;
@@ -755,12 +767,14 @@ __device__ __forceinline__ void opmse_dispatch(const OpMseGroup& g, float2* sh)
 #pragma unroll
     for (int i = 6; i >= 0; --i) if (i < g.n - 1 && blk >= g.start[i] - g.base) p = i;
     if (p == g.n - 1 && g.Wp) { opmse_packed(g, p, (long)blockIdx.x - g.start[p], sh); return; }
-    if (g.q[p].G) { opmse_gbody(g, p, sh); return; }                 // (uniform) the pair's collapsed operator G' is at hand
-    const int bt = g.bt[p];                                          // uniform per workgroup
-    if (bt == 32) opmse_small_body<8>(g, p, sh);
-    else if (bt == 16) opmse_body<16>(g, p, sh);
-    else if (bt == 8) opmse_body<8>(g, p, sh);
-    else opmse_body<4>(g, p, sh);
+    if (LEAN || g.q[p].G) { opmse_gbody(g, p, sh); return; }         // (uniform) the pair's collapsed operator G' is at hand
+    if constexpr (!LEAN) {
+        const int bt = g.bt[p];                                      // uniform per workgroup
+        if (bt == 32) opmse_small_body<8>(g, p, sh);
+        else if (bt == 16) opmse_body<16>(g, p, sh);
+        else if (bt == 8) opmse_body<8>(g, p, sh);
+        else opmse_body<4>(g, p, sh);
+    }
 }
 
 // workgroup ranges and LDS of the MSE part; `base` = workgroups of the launch in front of it (start[] are launch-wide indices)
@@ -816,7 +830,11 @@ namespace aefft {
 // weights change: one coalesced record per item, one memory round trip, the chain of small dependent products then runs out of
 // LDS.  The few middle-grid items (two small matrices each) keep the gather.
 // ------------------------------------------------------------------------------------------
-template <int NK> __global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g) { kspec_packed_body<NK>(g, blockIdx.x, blockIdx.y); }
+template <int NK> __global__ __launch_bounds__(256) void kspec_packed_kernel(const PackArgs g)
+{
+    extern __shared__ float2 pk_lds[];
+    kspec_packed_body<NK>(g, blockIdx.x, blockIdx.y, pk_lds);
+}
 
 void pack_blocks(PackArgs& g)
 {
@@ -831,8 +849,8 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
     if (g.nseg < 1 || g.nseg > 16 || g.L < 1 || g.L > 8 || g.E < 1 || (g.Nk != 3 && g.Nk != 5)) return hipErrorInvalidValue;
     pack_blocks(g);
     const dim3 grid((unsigned)g.nblk, (unsigned)pack_yblocks(g));
-    if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, 0, st>>>(g);
-    else kspec_packed_kernel<5><<<grid, 256, 0, st>>>(g);
+    if (g.Nk == 3) kspec_packed_kernel<3><<<grid, 256, kspec_packed_lds(3), st>>>(g);
+    else kspec_packed_kernel<5><<<grid, 256, kspec_packed_lds(5), st>>>(g);
     return hipGetLastError();
 }
 
@@ -843,6 +861,159 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 //  * the rest: a tile of CH_BT consecutive bins of grid j (1 <= j < L), threads = (bin, row group).  It recomputes the tile's
 //    ancestor chain A_1 .. A_j from the PLANAR spectra (small matrices; lanes along the bins: coalesced) and stores A_j.
 // No workgroup waits for another one; the only cost of the independence is the re-evaluation of a few small products.
+// ---- the per-bin item as a software pipeline over its record ----
+// The item's 2L stages are small dependent products whose matrices do NOT depend on the running vector: only the multiply waits for the
+// previous stage.  One output per thread and groups of 16 loads (chain_stage_rec) made every stage one to four memory round trips of its
+// own -- 24 us per item at cfg3, the long pole of the tail launch.  Here a STEP is up to CH_NE elements per thread of one stage's matrix,
+// thread <-> (row r, lane ks of KS <= 16 adjacent lanes: k = k0 + ks + KS u), every element of the record is loaded exactly once, and the loads
+// of step i + CH_DEPTH are issued before step i is computed: after the first round trip the stages run out of registers and LDS.  A stage
+// whose K range exceeds CH_NE * KS takes several steps (the row sums stay in registers); the KS partial sums of a row meet by lane exchange.
+// What keeps the pipeline a pipeline (hipcc's s_waitcnt insertion): every load is unconditional (clamped addresses, masked in the product;
+// the bias element rides along whether the item is the DC bin or not), so the number of loads in flight at each wait is static; the running
+// vectors are addressed off ONE LDS base (a select between two pointers turns the reads into flat loads, which wait for everything).
+// The step list is built by the host (chain_geometry).
+#ifndef AEFFT_X_CHAINPIPE
+#define AEFFT_X_CHAINPIPE 1
+#endif
+#ifndef AEFFT_X_CH_DEPTH
+#define AEFFT_X_CH_DEPTH 4
+#endif
+// acc += a * b as two v_pk_fma_f32 (the four FMAs of cfma2 in the same order per component: the same bits).  The steps below are bound by
+// their instruction count, not by latency -- where the latter holds (the stage-by-stage bodies) the packed form measured slower, DESIGN.md 6.
+#ifndef AEFFT_X_CH_PK
+#define AEFFT_X_CH_PK 1
+#endif
+__device__ __forceinline__ void cfma_pk(float2& acc, float2 a, float2 b)
+{
+#if AEFFT_X_CH_PK
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f r = {acc.x, acc.y};
+    const v2f av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(r) : "v"(av), "v"(bv));                          // + (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(av), "v"(bv));         // + (-a.y b.y, a.y b.x)
+    acc = make_float2(r.x, r.y);
+#else
+    cfma2(acc, a, b);
+#endif
+}
+constexpr int CH_NE = 4, CH_DEPTH = AEFFT_X_CH_DEPTH, CH_NB = CH_DEPTH + 1, CH_KSH_MAX = 4;
+// lane i <- lane i + N of the same 16-lane row (0 past the row's end)
+template <int N> __device__ __forceinline__ float dpp_row_shl(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+// desc: R (8 bits) | K (8) | k0 (7) | log2 KS (3) | last chunk of its stage | first chunk | encoder stage | level (3);  off: record offset of
+// the stage (24 bits) | bit 31: which of the two running vectors the stage reads
+__device__ __forceinline__ void chain_step_load(const ChainArgs& g, const float2* __restrict__ rec, const int i, float2 (&w)[CH_NE], float& bv)
+{
+    const unsigned d = g.st_desc[i], off = g.st_off[i] & 0xffffffu;
+    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
+    const unsigned tid = threadIdx.x;
+    const unsigned r = min(tid >> ksh, R - 1u), ks = tid & ((1u << ksh) - 1u);
+    const unsigned row = off + r * K, e0 = row + k0 + ks, elast = row + K - 1u;
+#pragma unroll
+    for (int u = 0; u < CH_NE; ++u) w[u] = ld8(rec, min(e0 + ((unsigned)u << ksh), elast));
+    const ChainLevel& lvl = g.lv[d >> 29];
+    const float* bias = (d >> 28) & 1u ? lvl.b : lvl.p;
+    bv = bias[r];
+}
+__device__ __forceinline__ void chain_step_compute(const ChainArgs& g, const int i, const float2 (&w)[CH_NE], const float bv, float2 (&acc)[OPC], float2* const Wl, const int t)
+{
+    static_assert(OPC == 4, "two 16-byte LDS accesses per row of V");
+    const unsigned d = g.st_desc[i], par = g.st_off[i] >> 31;
+    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
+    const unsigned tid = threadIdx.x;
+    const unsigned rr = tid >> ksh, ks = tid & ((1u << ksh) - 1u);
+    const bool valid = rr < R;
+    if ((d >> 27) & 1u) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
+    }
+    const float2* Vin = Wl + par * (CH_VMAX * OPC);
+#pragma unroll
+    for (int u = 0; u < CH_NE; ++u) {
+        const unsigned k = k0 + ks + ((unsigned)u << ksh);
+        const bool ok = valid && k < K;
+        const float2 wv = ok ? w[u] : make_float2(0.f, 0.f);
+        const float4* vp = reinterpret_cast<const float4*>(Vin + min(k, K - 1u) * OPC);
+        const float4 va = vp[0], vb = vp[1];
+        cfma_pk(acc[0], wv, make_float2(va.x, va.y)); cfma_pk(acc[1], wv, make_float2(va.z, va.w));
+        cfma_pk(acc[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc[3], wv, make_float2(vb.z, vb.w));
+    }
+    if (!((d >> 26) & 1u)) return;                                // (uniform) more chunks of this stage follow
+    // the KS <= 16 lanes of a row are adjacent and aligned inside a 16-lane DPP row: lane i += lane i + 2^j (row_shl, one v_add_f32_dpp each; lanes
+    // shifted in from outside the row read 0) leaves the row's sum in its lane ks == 0 -- the only one that stores.  (__shfl_xor is a
+    // ds_bpermute with its own wait per value: 48 of them per stage were 1.3 us of every stage.)
+    if (ksh > 0) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<1>(acc[c].x); acc[c].y += dpp_row_shl<1>(acc[c].y); }
+    }
+    if (ksh > 1) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<2>(acc[c].x); acc[c].y += dpp_row_shl<2>(acc[c].y); }
+    }
+    if (ksh > 2) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<4>(acc[c].x); acc[c].y += dpp_row_shl<4>(acc[c].y); }
+    }
+    if (ksh > 3) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<8>(acc[c].x); acc[c].y += dpp_row_shl<8>(acc[c].y); }
+    }
+    const bool enc = (d >> 28) & 1u;
+    const unsigned lv = d >> 29;
+    if (valid && ks == 0) {
+        const float scale = __frcp_rn((float)R);
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
+        if (t == 0) acc[OPC - 1].x += bv * ((float)g.lv[lv].Nx * (float)g.lv[lv].Ny);
+        const float4 o0 = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), o1 = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+        float4* vo = reinterpret_cast<float4*>(Wl + (par ^ 1u) * (CH_VMAX * OPC) + rr * OPC);
+        vo[0] = o0; vo[1] = o1;
+        if (!enc) {                                               // (uniform) a decoder stage: its rows are an output of the item, O_l[c][r] at bin t of the support
+            float2* O = g.lv[lv].O;
+            const unsigned Pc = (unsigned)g.Pc;
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) st8(O, ((unsigned)c * R + rr) * Pc + (unsigned)t, acc[c]);
+        }
+    }
+    __syncthreads();                                              // (uniform branch: every thread of the workgroup is here) the stage's output is complete
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(Wl + 2 * CH_VMAX * OPC)[(enc ? lv : 2 * g.L - 1 - lv) & 7] = wall_clock64();    // (in LDS: a global store here would drain the pipeline it times)
+#endif
+}
+// straight-line code, one copy per step, the exits nested (a template recursion): with a LOOP around the rotation hipcc's wait insertion merges
+// the loop's entry and back edge into a vmcnt(0) at the header -- a drained pipeline every CH_NB steps -- and a rolled loop would index the
+// register sets dynamically (scratch)
+template <int I>
+__device__ __forceinline__ void chain_steps(const ChainArgs& g, const float2* __restrict__ rec, const int n, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
+                                            float2 (&acc)[OPC], float2* const Wl, const int t)
+{
+    if constexpr (I < CH_MAXSTEPS) {
+        if (I >= n) return;                                       // (uniform)
+        chain_step_load(g, rec, min(I + CH_DEPTH, n - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
+        chain_step_compute(g, I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
+        chain_steps<I + 1>(g, rec, n, w, bv, acc, Wl, t);
+    }
+}
+__device__ __forceinline__ void chain_item_pipelined(const ChainArgs& g, const int t, float2* Wl)
+{
+    const float2* rec = g.Wp + (long)t * g.E;
+    const int n = g.st_n;
+    float2 w[CH_NB][CH_NE];
+    float bv[CH_NB];
+#pragma unroll
+    for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, min(j, n - 1), w[j], bv[j]);
+    for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+    __syncthreads();
+    float2 acc[OPC];
+    chain_steps<0>(g, rec, n, w, bv, acc, Wl, t);
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+    if (threadIdx.x == 0 && g_wgtime && blockIdx.x < WGT_MAX)
+        for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 2 * CH_VMAX * OPC)[k];
+#endif
+}
+
 constexpr int CH_BT = 8;
 constexpr size_t CHAIN_BIN_LDS = sizeof(float2) * 2 * CH_VMAX * OPC;
 // bx: the workgroup's index inside the chain part of the launch; Wl: dynamic LDS (per-bin items: two running vectors; planar tiles:
@@ -851,6 +1022,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
 {
     const int tid = threadIdx.x;
     const int L = g.L;
+    if (AEFFT_X_CHAINPIPE && (long)bx < g.Pc && g.st_n > 0) { chain_item_pipelined(g, bx, Wl); return; }      // (st_n == 0: more steps than the straight-line pipeline has copies)
     if ((long)bx < g.Pc) {
         float2* V[2] = {Wl, Wl + CH_VMAX * OPC};
         const int t = bx;
@@ -860,6 +1032,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
         int off = 0, si = 0;
         auto run = [&](int R, int K, float scale, const float* bias, float NN, float2* out) {
             __syncthreads();                                         // the previous stage's output is complete
+            AEFFT_WGSTAMP(4, si & 7);
             chain_stage_rec(rec + off, V[si & 1], V[(si + 1) & 1], R, K, scale, bias, NN, dc, out, g.Pc, t);
             off += (R * K + 1) & ~1; ++si;
         };
@@ -942,6 +1115,29 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
         if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX) return hipErrorInvalidValue;
         if (l + 1 < g.L && (size_t)2 * g.lv[l].dM * OPC * CH_BT > CH_WL) return hipErrorInvalidValue;     // planar tiles: two V tiles share the LDS buffer
     }
+    {
+        // the per-bin item's step list (chain_item_pipelined): stage si = level si's encoder matrix, then the decoders from the innermost level out
+        int n = 0; unsigned off = 0;
+        for (int si = 0; si < 2 * g.L; ++si) {
+            const bool enc = si < g.L;
+            const int l = enc ? si : 2 * g.L - 1 - si;
+            const int R = enc ? g.lv[l].dM : g.lv[l].dD, K = enc ? g.lv[l].dD : g.lv[l].dM;
+            int ksh = 0;                                             // KS = min(largest power of two <= 256 / R, smallest power of two >= K, 16)
+            while (ksh < CH_KSH_MAX && (2 << ksh) * R <= 256 && (1 << ksh) < K) ++ksh;
+            const int kc = CH_NE << ksh;
+            for (int k0 = 0; k0 < K; k0 += kc) {
+                if (off >= (1u << 24) || k0 > 127) return hipErrorInvalidValue;
+                if (n >= CH_MAXSTEPS) { ++n; continue; }             // (counted only: the item then runs stage by stage, chain_stage_rec)
+                g.st_off[n] = off | ((unsigned)(si & 1) << 31);
+                g.st_desc[n] = (unsigned)R | ((unsigned)K << 8) | ((unsigned)k0 << 16) | ((unsigned)ksh << 23) | ((k0 + kc >= K ? 1u : 0u) << 26) |
+                               ((k0 == 0 ? 1u : 0u) << 27) | ((enc ? 1u : 0u) << 28) | ((unsigned)l << 29);
+                ++n;
+            }
+            off += (unsigned)((R * K + 1) & ~1);
+        }
+        g.st_n = n <= CH_MAXSTEPS ? n : 0;
+        if ((double)4 * CH_VMAX * (double)g.Pc >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit element offsets of the output stores)
+    }
     long total = g.Pc;
     for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
     g.tile_start[g.L] = (int)total;
@@ -950,7 +1146,7 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
     g.vt_elems = rmax * OPC * CH_BT;
     *nblocks = total;
-    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS);
+    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS + 64 /* (experiment builds: stage stamps) */);
     return hipSuccess;
 }
 
@@ -972,8 +1168,14 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
 // the OTHER set of operator buffers; the MSE reads the operators of the step that is ending.  Nothing in the launch depends on
 // anything else in it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
+// (LEAN: 80 registers -- six workgroups per CU instead of four; the launch is bound by its resident workgroups: 3 700 of them, 4-20 us each)
+#ifndef AEFFT_X_TAIL_W
+#define AEFFT_X_TAIL_W 6
+#endif
+template <bool LEAN>
+__global__ __launch_bounds__(256, LEAN ? AEFFT_X_TAIL_W : 4) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
 {
+    AEFFT_WGTIME(4);
     extern __shared__ float2 sh[];
     if ((int)blockIdx.x < nchain) { chain_body(ch, blockIdx.x, sh); return; }
     if ((int)blockIdx.x >= nupd_start) {
@@ -984,7 +1186,7 @@ __global__ __launch_bounds__(256, 4) void tail_kernel(const OpMseGroup g, const 
         update_weights_part(ug.a[p], blk - ug.start[p]);
         return;
     }
-    opmse_dispatch(g, sh);
+    opmse_dispatch<LEAN>(g, sh);
 }
 
 static UpdateGroup g_tail_ug_none{};
@@ -1004,14 +1206,25 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st, ChainArgs* chain, c
         ug.start[ug.n] = nupd;
     }
     const size_t lds = std::max(lds_c, lds_m);
+#ifndef AEFFT_X_LEANTAIL
+#define AEFFT_X_LEANTAIL 1
+#endif
+    bool lean = AEFFT_X_LEANTAIL != 0;
+    for (int i = 0; i < g.n && lean; ++i) lean = g.q[i].G != nullptr || (i == g.n - 1 && g.Wp != nullptr);      // (after opmse_geometry: Wp is null unless the innermost pair goes packed)
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = lean ? hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const long total = nchain + nmse + nupd;
     if (total >= (1L << 31)) return hipErrorInvalidValue;
-    tail_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
+    if (lean) tail_kernel<true><<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
+    else tail_kernel<false><<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
     return hipGetLastError();
 }
 
 }  // namespace aefft
+
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+extern "C" int aefft_debug_wgtime_opform(void* p) { return aefft::wgtime_set_tu(p); }
+#endif

@@ -40,17 +40,22 @@ __device__ __forceinline__ float2 phase(const float2* tw, int pos, int off, int 
 // plane at `dst` ([Nx][Nyr], j added by the caller).  (NxB, NyB): the grid the phases are taken on -- row i / column j of the
 // [Nx][Ny/2+1] output are the images map_up_row / map_up_col of pool_fft's crop in it (the spectrum sampled where the NEXT pair's
 // grid lands: the chain's planar tiles read nothing else); NxB == Nx: the plane's own grid.
+// the column phases of thread column j (offsets 1 .. NL/2): gathers from the global twiddle table -- a memory round trip, so the callers ask for
+// them BEFORE they stage the taps (the G' workgroups had it behind their tap products: 1.5-2 us of every such workgroup)
+template <int NL>
+__device__ __forceinline__ void kspec_col_phases(const float2* __restrict__ tw, int j, int Ny, int NyB, float2 (&cp)[NL / 2 > 0 ? NL / 2 : 1])
+{
+    const int jB = map_up_col(j, Ny, NyB);
+#pragma unroll
+    for (int l = 0; l < NL / 2; ++l) cp[l] = phase_tw(tw, jB, l + 1, NyB);
+}
 template <int NK, int NL>
-__device__ __forceinline__ void kspec_rows(const float* __restrict__ c, float2* __restrict__ dst, const float2* __restrict__ tw, const float2* __restrict__ rowph,
-                                           int Ny, int NyB, int Nyr, int j, int nrows)
+__device__ __forceinline__ void kspec_rows(const float* __restrict__ c, float2* __restrict__ dst, const float2 (&cp)[NL / 2 > 0 ? NL / 2 : 1], const float2* __restrict__ rowph,
+                                           int Nyr, int nrows)
 {
     constexpr int H = NK / 2, HL = NL / 2;
     float2 v0, sv[H > 0 ? H : 1], dv[H > 0 ? H : 1];
     {
-        float2 cp[HL > 0 ? HL : 1];
-        const int jB = map_up_col(j, Ny, NyB);
-#pragma unroll
-        for (int l = 0; l < HL; ++l) cp[l] = phase_tw(tw, jB, l + 1, NyB);
         float2 v[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -98,7 +103,10 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
     float* part = work;                                  // [slices][np*T][T]: takes the place of fs | cs once every slice has its sums in registers
     const unsigned nk = (unsigned)(dM * dD * KK);        // f follows c (c|f, dck|dfk, Dc|Df: each pair contiguous); element offsets fit 32 bits
     const int nf = dM * KK, nc = np * dM * KK;
-    constexpr int U = 16;                                // loads per array and batch (registers: the launch's other workgroups pay for every one)
+#ifndef AEFFT_X_GT_U
+#define AEFFT_X_GT_U 16
+#endif
+    constexpr int U = AEFFT_X_GT_U;                      // loads per array and batch (registers: the launch's other workgroups pay for every one)
     for (int t0 = 0; t0 < nf + nc; t0 += U * NT) {
         float w[U], gq[U], dq[U];
 #pragma unroll
@@ -130,6 +138,7 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
         }
     }
     __syncthreads();
+    AEFFT_WGSTAMP(3, 0);
     const int items = np * T;
     int nsl = NT / items;
     if (nsl > dM) nsl = dM;
@@ -162,11 +171,13 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
         }
     }
     __syncthreads();                                     // every read of fs | cs is done
+    AEFFT_WGSTAMP(3, 1);
     if (work_thr) {
 #pragma unroll
         for (int y = 0; y < T; ++y) part[(sl * items + it) * T + y] = acc[y];
     }
     __syncthreads();
+    AEFFT_WGSTAMP(3, 2);
     for (int t2 = tid; t2 < items * T; t2 += NT) {
         float a = part[t2];
         for (int s2 = 1; s2 < nsl; ++s2) a += part[s2 * items * T + t2];
@@ -192,6 +203,9 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
     float* taps_s = reinterpret_cast<float*>(rowph + rows_per_chunk * H);      // [ppb][NK*NL]: the planes' taps, staged once per workgroup
     const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
+    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    float2 cp[NL / 2 > 0 ? NL / 2 : 1];
+    kspec_col_phases<NL>(tw, j, Ny, NyB, cp);
     for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, map_up_row(i0 + t / H, Nx, NxB), t % H + 1, NxB);
     {
         // (through the pending update when there is one -- uniform --: w - clip_step(g, D), TapUpd)
@@ -214,10 +228,10 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
         }
     }
     __syncthreads();
-    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    AEFFT_WGSTAMP(3, 0);
     const long plane = (long)bx * ppb + pl;
     if (pl >= ppb || plane >= planes) return;
-    kspec_rows<NK, NL>(taps_s + pl * (NK * NL), K + (plane * Nx + i0) * (long)Nyr + j, tw, rowph, Ny, NyB, Nyr, j, nrows);
+    kspec_rows<NK, NL>(taps_s + pl * (NK * NL), K + (plane * Nx + i0) * (long)Nyr + j, cp, rowph, Nyr, nrows);
 }
 
 // the G' form of kspec_body: workgroup = (d', tile of ppb d's) x row chunk; the taps come from gtaps_stage
@@ -232,16 +246,19 @@ __device__ __forceinline__ void gspec_gbody(const GtapSrc& gs, float2* __restric
     float* work = taps_s + ppb * TT;
     const int i0 = by * rows_per_chunk;
     const int nrows = min(rows_per_chunk, Nx - i0);
+    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    float2 cp[H];
+    kspec_col_phases<T>(tw, j, Ny, Ny, cp);
     for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, i0 + t / H, t % H + 1, Nx);
     const int tiles = (gs.dD + ppb - 1) / ppb;
     const int dp = bx / tiles, d0 = (bx - dp * tiles) * ppb;
     const int np = min(ppb, gs.dD - d0);
     gtaps_stage<NK>(gs, upd, dp, d0, np, taps_s, work);
     __syncthreads();
-    const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
+    AEFFT_WGSTAMP(3, 3);
     if (pl >= np) return;
     const long plane = (long)dp * gs.dD + d0 + pl;
-    kspec_rows<T, T>(taps_s + pl * TT, G + (plane * Nx + i0) * (long)Nyr + j, tw, rowph, Ny, Ny, Nyr, j, nrows);
+    kspec_rows<T, T>(taps_s + pl * TT, G + (plane * Nx + i0) * (long)Nyr + j, cp, rowph, Nyr, nrows);
 }
 
 template <int NK, int NL>
@@ -255,8 +272,12 @@ __global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ ke
 
 // all pairs' kernel spectra in one launch: problem p owns workgroups [start[p], start[p+1]), plane groups fastest
 template <int NK, int NL>
-__global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk, const BiasUpdGroup bu, const int nbias_start)
+#ifndef AEFFT_X_KSPEC_W
+#define AEFFT_X_KSPEC_W 1
+#endif
+__global__ __launch_bounds__(320, AEFFT_X_KSPEC_W) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk, const BiasUpdGroup bu, const int nbias_start)
 {
+    AEFFT_WGTIME(3);
     extern __shared__ float2 lds[];
     if ((int)blockIdx.x >= nbias_start) {
         // last of all: the bias half of a fused update (nothing in this launch reads b or p), one workgroup per pair
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(320) void kspec_group_kernel(const PrunedGroup g, c
         // trailing workgroups: the bin-major copy of the spectra for the operator chain (opform_device.h), from the same taps
         if constexpr (NK == NL && (NK == 3 || NK == 5)) {
             const int lin = blockIdx.x - g.start[g.n];
-            kspec_packed_body<NK>(pk, lin % pk.nblk, lin / pk.nblk);
+            kspec_packed_body<NK>(pk, lin % pk.nblk, lin / pk.nblk, lds);
         }
         return;
     }
@@ -430,6 +451,7 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         for (int u = 0; u < 3; ++u) { const int t = t0 + u * NT + threadIdx.x; if (t < Nyr * NLc) colph[(t / NLc) * NL + HLc + t % NLc] = v[u]; }
     }
     __syncthreads();
+    AEFFT_WGSTAMP(1, 0);
     // t_k = sum_i d_i e^{+i th_k(i)} for the offsets kap = k - H.  The offsets come in conjugate pairs: d*p and d*conj(p) share their
     // four products, so per pair the sums A = sum dx px, B = sum dy py, C = sum dx py, E = sum dy px are accumulated (4 FMAs per
     // element instead of 8) and t_{+kap} = (A - B, C + E), t_{-kap} = (A + B, E - C) at the end; kap = 0 is the plain sum.
@@ -473,15 +495,25 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         for (int k = 0; k < NK; ++k) { tre[k * TS + threadIdx.x] = t[k].x; tim[k * TS + threadIdx.x] = t[k].y; }
     }
     __syncthreads();
+    AEFFT_WGSTAMP(1, 1);
     if (active && s == 0) {                               // row slices -> slice 0, in slice order
+        // (every read of a slice step issued before the first add: a rolled loop over k and s2 is one LDS round trip per element -- 2.5 us of
+        // this kernel's 15)
+        float a[NK], b[NK];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            float a = tre[k * TS + rem], b = tim[k * TS + rem];
-            for (int s2 = 1; s2 < S; ++s2) { a += tre[k * TS + s2 * per + rem]; b += tim[k * TS + s2 * per + rem]; }
-            tre[k * TS + rem] = a; tim[k * TS + rem] = b;
+        for (int k = 0; k < NK; ++k) { a[k] = tre[k * TS + rem]; b[k] = tim[k * TS + rem]; }
+        for (int s2 = 1; s2 < S; ++s2) {
+            float a2[NK], b2[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { a2[k] = tre[k * TS + s2 * per + rem]; b2[k] = tim[k * TS + s2 * per + rem]; }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { a[k] += a2[k]; b[k] += b2[k]; }
         }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { tre[k * TS + rem] = a[k]; tim[k * TS + rem] = b[k]; }
     }
     __syncthreads();
+    AEFFT_WGSTAMP(1, 2);
     // g[k][l] = sum_j w_j Re( t_k[j] e^{+2 pi i j lam_l / Ny} ).  The column offsets come in conjugate pairs as well: a task is
     // (plane, k, |lam|) and accumulates P = sum w tre cx and Q = sum w tim cy, g[+lam] = P - Q, g[-lam] = P + Q.  The columns of a
     // plane are split over JS threads per task (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums
@@ -500,15 +532,28 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         const int k = kl / (HL + 1), lam = kl - k * (HL + 1);
         float pp = 0.f, qq = 0.f;
         const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
-        for (int jj = j0; jj < j1; ++jj) {
-            const float2 cp = colph[jj * NL + HL + lam];
-            const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
-            pp = fmaf(wj * tre[k * TS + p2 * Nyr + jj], cp.x, pp);
-            qq = fmaf(wj * tim[k * TS + p2 * Nyr + jj], cp.y, qq);
+        // (batches of 8 columns, reads first: the rolled loop was one LDS round trip per column; same order of the adds)
+        for (int jb = j0; jb < j1; jb += 8) {
+            float2 cp[8]; float tr[8], ti[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = min(jb + u, j1 - 1);
+                cp[u] = colph[jj * NL + HL + lam]; tr[u] = tre[k * TS + p2 * Nyr + jj]; ti[u] = tim[k * TS + p2 * Nyr + jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = jb + u;
+                if (jj < j1) {
+                    const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
+                    pp = fmaf(wj * tr[u], cp[u].x, pp);
+                    qq = fmaf(wj * ti[u], cp[u].y, qq);
+                }
+            }
         }
         part[2 * it] = pp; part[2 * it + 1] = qq;
     }
     __syncthreads();
+    AEFFT_WGSTAMP(1, 3);
     for (int o = threadIdx.x; o < nout; o += NT) {
         const int p2 = o / TT, kl = o - p2 * TT;
         const long pln = (long)bx * ppb + p2;
@@ -518,14 +563,19 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         const float sg = l >= HL ? -1.f : 1.f;
         const float* pt = part + 2 * ((p2 * TK + k * (HL + 1) + lam) * JS);
         float a = 0.f;
+#pragma unroll 4
         for (int js = 0; js < JS; ++js) a += pt[2 * js] + sg * pt[2 * js + 1];
         g[(pln * nchunks + chunk) * TT + kl] = a * scale;       // [plane][chunk][tap]: the consumer adds the chunks in order
     }
 }
 
 template <int NK, int NL, int NT>
-__global__ __launch_bounds__(NT) void kgrad_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const BiasGradGroup bg)
+#ifndef AEFFT_X_KGRAD_W
+#define AEFFT_X_KGRAD_W 1
+#endif
+__global__ __launch_bounds__(NT, AEFFT_X_KGRAD_W) void kgrad_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const BiasGradGroup bg)
 {
+    AEFFT_WGTIME(1);
     extern __shared__ float2 lds[];
     if ((int)blockIdx.x >= g.start[g.n]) {
         // trailing workgroups: the independent DC-bin terms (db, dp, es) of every pair ride along instead of costing a launch
@@ -676,7 +726,13 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
         const PrunedProb& q = g.q[p];
         // <= 64 rows per workgroup for every problem (a launch-wide chunk count gave the big grids 128-row workgroups on half their
         // lanes: 23.7 us against 21.5 us at cfg3; 32 rows: 22.0, 16 rows: 24.9)
-        const int chunks = (q.Nx + 63) / 64;
+        // (G' problems with 32-row chunks -- their workgroups stand behind a tap-product stage and are the launch's long pole --: each is 2-3 us
+        // shorter, but there are twice as many for the same 768 resident slots: 18.8-19.1 vs 18.7-18.9 us for the launch, step +2 us.  64 for all.)
+#ifndef AEFFT_X_GROWS
+#define AEFFT_X_GROWS 64
+#endif
+        const int rmax = g.gsrc[p].f ? AEFFT_X_GROWS : 64;
+        const int chunks = (q.Nx + rmax - 1) / rmax;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
         if (g.gsrc[p].f) {
             // G' problem (gspec_gbody): plane groups (d', tile of ppb d's); LDS = row phases | taps | f' | c' tile | slice partials
@@ -708,7 +764,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
     if (threads > 320) return hipErrorInvalidValue;
     int extra = 0;
-    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); }
+    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); lds = std::max(lds, kspec_packed_lds(NK)); }
     const int nb = bu ? bu->n : 0;
     kspec_group_kernel<NK, NL><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
     return hipGetLastError();
@@ -857,3 +913,7 @@ hipError_t launch_kgrad(const float2* D, float* g, float* part, const float2* tw
 }
 
 }  // namespace aefft
+
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+extern "C" int aefft_debug_wgtime_pruned(void* p) { return aefft::wgtime_set_tu(p); }
+#endif

@@ -12,6 +12,7 @@
 // back per step at cfg3) never exist.  (Likewise the per-bin product G = F.C/(dM dD) used by the post-update MSE is the
 // spectrum of the (2Nk-1) x (2Nl-1) kernel sum_m f[d'][m] (*) c[m][d] / (dM dD): gspec_gbody, pruned_kernels.hip.)
 #include "internal.h"
+#include "device_util.h"
 #include "update_device.h"
 #include <algorithm>
 
@@ -23,9 +24,13 @@ namespace aefft {
 // for NK*NK FMAs (a 1-D valid correlation in registers), i.e. ~0.5 LDS reads per FMA instead of 2.
 // Blocks of a problem: [0, dD*mt) -> g_c, [dD*mt, 2*dD*mt) -> g_f, mt = ceil(dM/TM).
 constexpr int WG_DB = 32;            // inner channels staged per block (a multiple of the 8 slices)
+#ifndef AEFFT_X_WGRAD_W
+#define AEFFT_X_WGRAD_W 1
+#endif
 template <int NK>
-__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
+__global__ __launch_bounds__(256, AEFFT_X_WGRAD_W) void wgrad_taps_kernel(const WgradGroup g)
 {
+    AEFFT_WGTIME(2);
     constexpr int T = 2 * NK - 1, KK = NK * NK, TT = T * T, SL = 8, TM = 256 / (NK * SL);    // 6 outer channels x 8 d1 slices per workgroup for 5x5 (4 slices: 18.1 us, 8: 14.2 us at cfg3)
     extern __shared__ float sh[];                       // Qs[dD][TT] | ws[dD][TM][KK] | red[256][NK]
     if ((int)blockIdx.x == g.start[g.n]) {              // (trailing workgroup, only launched for it) the previous step's deferred MSE sums
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
             for (int u = 0; u < 24; ++u) { const int t = t0 + u * 256 + threadIdx.x; if (t < nb * TM * KK) ws[t] = v[u]; }
         }
         __syncthreads();
+        if (db == 0) AEFFT_WGSTAMP(2, 0);
         if (s < SL && m < dM) {
             for (int d1 = s; d1 < nb; d1 += SL) {
                 const float* wb = ws + (d1 * TM + ml) * KK;
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradGroup g)
 #pragma unroll
     for (int l = 0; l < NK; ++l) red[threadIdx.x * NK + l] = acc[l];
     __syncthreads();
+    AEFFT_WGSTAMP(2, 1);
     if (s != 0 || m >= dM) return;
 #pragma unroll
     for (int l = 0; l < NK; ++l) {
@@ -187,3 +194,7 @@ hipError_t launch_wgrad_taps_group(WgradGroup& g, int Nk, hipStream_t st)
 }
 
 }  // namespace aefft
+
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+extern "C" int aefft_debug_wgtime_weight(void* p) { return aefft::wgtime_set_tu(p); }
+#endif
