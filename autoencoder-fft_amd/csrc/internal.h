@@ -28,7 +28,7 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
 // opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
 // A[OPIN_COLS-1][d][t] + sum_{j<D0} A[j][d][t] * Xf[b][j][u(t)], A [OPIN_COLS][D0][Nxi*(Nyi/2+1)], Xf [B][D0][Nx0*(Ny0/2+1)]
 constexpr int OPIN_COLS = 4;
-constexpr int CH_MAXSTEPS = 12;       // steps of a per-bin chain item (chain_geometry)
+constexpr int CH_MAXSTEPS = 40;       // most steps of a per-bin chain item (chain_geometry's table; cfg5: 26)
 constexpr int CH_VMAX = 128;          // most rows of a matrix the packed-record kernels (chain, innermost-pair MSE) take
 struct OpIn { const float2* A; const float2* Xf; int D0, Nx0, Ny0; };
 hipError_t launch_c2r(const float2* in, float* out, float2* mid, long planes, int Nxi, int Nyi,

@@ -896,7 +896,7 @@ __device__ __forceinline__ void cfma_pk(float2& acc, float2 a, float2 b)
     cfma2(acc, a, b);
 #endif
 }
-constexpr int CH_NE = 4, CH_DEPTH = AEFFT_X_CH_DEPTH, CH_NB = CH_DEPTH + 1, CH_KSH_MAX = 4;
+constexpr int CH_NE = 4, CH_DEPTH = AEFFT_X_CH_DEPTH, CH_NB = CH_DEPTH + 1, CH_KSH_MAX = 4, CH_BLOCK = 12;
 // lane i <- lane i + N of the same 16-lane row (0 past the row's end)
 template <int N> __device__ __forceinline__ float dpp_row_shl(float v)
 {
@@ -986,14 +986,14 @@ __device__ __forceinline__ void chain_step_compute(const ChainArgs& g, const int
 // the loop's entry and back edge into a vmcnt(0) at the header -- a drained pipeline every CH_NB steps -- and a rolled loop would index the
 // register sets dynamically (scratch)
 template <int I>
-__device__ __forceinline__ void chain_steps(const ChainArgs& g, const float2* __restrict__ rec, const int n, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
+__device__ __forceinline__ void chain_steps(const ChainArgs& g, const float2* __restrict__ rec, const int base, const int nb, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
                                             float2 (&acc)[OPC], float2* const Wl, const int t)
 {
-    if constexpr (I < CH_MAXSTEPS) {
-        if (I >= n) return;                                       // (uniform)
-        chain_step_load(g, rec, min(I + CH_DEPTH, n - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
-        chain_step_compute(g, I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
-        chain_steps<I + 1>(g, rec, n, w, bv, acc, Wl, t);
+    if constexpr (I < CH_BLOCK) {
+        if (I >= nb) return;                                      // (uniform)
+        chain_step_load(g, rec, base + min(I + CH_DEPTH, nb - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
+        chain_step_compute(g, base + I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
+        chain_steps<I + 1>(g, rec, base, nb, w, bv, acc, Wl, t);
     }
 }
 __device__ __forceinline__ void chain_item_pipelined(const ChainArgs& g, const int t, float2* Wl)
@@ -1002,12 +1002,18 @@ __device__ __forceinline__ void chain_item_pipelined(const ChainArgs& g, const i
     const int n = g.st_n;
     float2 w[CH_NB][CH_NE];
     float bv[CH_NB];
-#pragma unroll
-    for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, min(j, n - 1), w[j], bv[j]);
-    for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
-    __syncthreads();
     float2 acc[OPC];
-    chain_steps<0>(g, rec, n, w, bv, acc, Wl, t);
+    // blocks of CH_BLOCK straight-line steps (cfg3: one block); the pipeline drains and refills between blocks
+    for (int base = 0; base < n; base += CH_BLOCK) {
+        const int nb = min(n - base, CH_BLOCK);
+#pragma unroll
+        for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, base + min(j, nb - 1), w[j], bv[j]);
+        if (base == 0) {
+            for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+            __syncthreads();
+        }
+        chain_steps<0>(g, rec, base, nb, w, bv, acc, Wl, t);
+    }
 #if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
     if (threadIdx.x == 0 && g_wgtime && blockIdx.x < WGT_MAX)
         for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 2 * CH_VMAX * OPC)[k];
@@ -1022,18 +1028,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
 {
     const int tid = threadIdx.x;
     const int L = g.L;
-    if (AEFFT_X_CHAINPIPE && (long)bx < g.Pc && g.st_n > 0) { chain_item_pipelined(g, bx, Wl); return; }      // (st_n == 0: more steps than the straight-line pipeline has copies)
+    if (AEFFT_X_CHAINPIPE && (long)bx < g.Pc && g.st_n > 0) { chain_item_pipelined(g, bx, Wl); return; }      // (st_n == 0: more steps than the step table holds)
     if ((long)bx < g.Pc) {
-        float2* V[2] = {Wl, Wl + CH_VMAX * OPC};
         const int t = bx;
         const bool dc = t == 0;
         const float2* rec = g.Wp + (long)t * g.E;
-        for (int i = tid; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; V[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+        for (int i = tid; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
         int off = 0, si = 0;
         auto run = [&](int R, int K, float scale, const float* bias, float NN, float2* out) {
             __syncthreads();                                         // the previous stage's output is complete
             AEFFT_WGSTAMP(4, si & 7);
-            chain_stage_rec(rec + off, V[si & 1], V[(si + 1) & 1], R, K, scale, bias, NN, dc, out, g.Pc, t);
+            // (the two running vectors as offsets off ONE LDS base: a select between two pointers compiles to flat loads)
+            chain_stage_rec(rec + off, Wl + (si & 1) * (CH_VMAX * OPC), Wl + ((si + 1) & 1) * (CH_VMAX * OPC), R, K, scale, bias, NN, dc, out, g.Pc, t);
             off += (R * K + 1) & ~1; ++si;
         };
         for (int j = 1; j < L; ++j) { const ChainLevel& w = g.lv[j - 1]; run(w.dM, w.dD, 1.0f / (float)w.dM, w.b, (float)w.Nx * (float)w.Ny, nullptr); }
@@ -1052,8 +1058,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
     const long s = min(s0 + bl, lj.P - 1);
     const bool ok = s0 + bl < lj.P;
     // V tiles in LDS: [row][col][bin], ping-pong halves of Wl
-    float2* Vt[2] = {Wl, Wl + g.vt_elems};
-    for (int i = tid; i < OPC * OPC * CH_BT; i += 256) { const int b2 = i % CH_BT, c = (i / CH_BT) % OPC, k = i / (CH_BT * OPC); Vt[0][i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); (void)b2; }
+    // (addressed as offsets off ONE LDS base: a select between two pointers compiles to flat loads, which wait for every counter)
+    for (int i = tid; i < OPC * OPC * CH_BT; i += 256) { const int b2 = i % CH_BT, c = (i / CH_BT) % OPC, k = i / (CH_BT * OPC); Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); (void)b2; }
     // (a ROLLED loop over the levels: unrolled, the seven copies of the stage body cost 121 registers -- half the occupancy of the
     // launch, which hosts the per-bin items and the MSE as well; the level's descriptor is a uniform, scalar-loaded index)
 #pragma unroll 1
@@ -1064,8 +1070,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
         const long sbm = map_up(s, lj.Nx, lj.Ny, w.Nx, w.Ny);
         const int R = w.dM, K = w.dD;
         const float scale = 1.0f / (float)w.dM, NN = (float)w.Nx * (float)w.Ny;
-        const float2* Vin = Vt[(i - 1) & 1];
-        float2* Vout = Vt[i & 1];
+        const float2* Vin = Wl + ((i - 1) & 1) * g.vt_elems;
+        float2* Vout = Wl + (i & 1) * g.vt_elems;
         __syncthreads();
         for (int r = ry; r < R; r += RT) {
             float2 acc[OPC];
