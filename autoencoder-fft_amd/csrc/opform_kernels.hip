@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, AEFFT_X_MSGRAD_W) void msgrad_kernel(const Sgr
     }
     __syncthreads();
     AEFFT_WGSTAMP(0, 0);
+#pragma unroll 3
     for (int i = tid; i < 9 * BT; i += 256) {                       // slices -> one sum, in slice order (deterministic)
         const int e = i / BT, b2 = i - e * BT;
         float2 a = red[e * BT + b2];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256, AEFFT_X_MSGRAD_W) void msgrad_kernel(const Sgr
     }
     const float fB = (float)B, iB = 1.0f / (float)B;
     const bool store_m = g.Mout != nullptr && p == 0;                               // (uniform) pair 0: its grid is the moments' grid
+#pragma unroll 4
     for (int i = tid; i < 16 * BT; i += 256) {
         const int e = i / BT, b2 = i - e * BT;
         const int j = e >> 2, k = e & 3;

@@ -152,7 +152,11 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
     for (int y = 0; y < T; ++y) acc[y] = 0.f;
     if (work_thr) {
         const int i = it / T, tx = it - i * T;
-#pragma unroll 2
+        // (the m loop rolled: unrolled by 2 its LDS reads are hoisted into 153 registers for the spectra launch -- 3 workgroups per CU; rolled 128 -- 4)
+#ifndef AEFFT_X_GT_MU
+#define AEFFT_X_GT_MU 1
+#endif
+#pragma unroll AEFFT_X_GT_MU
         for (int m = sl; m < dM; m += nsl) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -518,39 +522,48 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
     // (plane, k, |lam|) and accumulates P = sum w tre cx and Q = sum w tim cy, g[+lam] = P - Q, g[-lam] = P + Q.  The columns of a
     // plane are split over JS threads per task (a 129-column plane would otherwise be one 129-step serial LDS chain), partial sums
     // combined in slice order.
-    constexpr int HL = NL / 2, TK = NK * (HL + 1);
-    static_assert(NL % 2 == 1, "symmetric offsets");
-    const int nout = ppb * TT, ntask = ppb * TK;
+    constexpr int HL = NL / 2;
+    static_assert(NL % 2 == 1 && NLc == HL + 1, "symmetric offsets");
+    // A task is (plane, k, slice of the plane's columns) and accumulates P[lam] = sum w tre cx, Q[lam] = sum w tim cy for ALL |lam| at once: t_k[j]
+    // is read once per column instead of once per (column, lam) -- the stage is bound by its LDS reads (one task per (k, |lam|): 2.4-5 us of the
+    // kernel's 15) -- and the reads of four columns are issued before their FMAs.
+    const int nout = ppb * TT, ntask = ppb * NK;
     int JS = NT / ntask;
     if (JS < 1) JS = 1;
     if (JS > 16) JS = 16;
     const int jlen = (Nyr + JS - 1) / JS;
-    float* part = tim + NK * TS;                          // [ntask][JS][2], after the t arrays
+    float* part = tim + NK * TS;                          // [ntask][JS][NLc][2], after the t arrays
     for (int it = threadIdx.x; it < ntask * JS; it += NT) {
         const int o = it / JS, js = it - o * JS;
-        const int p2 = o / TK, kl = o - p2 * TK;
-        const int k = kl / (HL + 1), lam = kl - k * (HL + 1);
-        float pp = 0.f, qq = 0.f;
-        const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
-        // (batches of 8 columns, reads first: the rolled loop was one LDS round trip per column; same order of the adds)
-        for (int jb = j0; jb < j1; jb += 8) {
-            float2 cp[8]; float tr[8], ti[8];
+        const int p2 = o / NK, k = o - p2 * NK;
+        float pp[NLc], qq[NLc];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+        for (int lam = 0; lam < NLc; ++lam) pp[lam] = qq[lam] = 0.f;
+        const int j0 = js * jlen, j1 = min(Nyr, j0 + jlen);
+        const float* tr0 = tre + k * TS + p2 * Nyr;
+        const float* ti0 = tim + k * TS + p2 * Nyr;
+        for (int jb = j0; jb < j1; jb += 4) {
+            float tr[4], ti[4]; float2 cp[4][NLc];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 const int jj = min(jb + u, j1 - 1);
-                cp[u] = colph[jj * NL + HL + lam]; tr[u] = tre[k * TS + p2 * Nyr + jj]; ti[u] = tim[k * TS + p2 * Nyr + jj];
+                tr[u] = tr0[jj]; ti[u] = ti0[jj];
+#pragma unroll
+                for (int lam = 0; lam < NLc; ++lam) cp[u][lam] = colph[jj * NL + HL + lam];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int jj = jb + u;
                 if (jj < j1) {
                     const float wj = (jj == 0 || jj == Ny / 2) ? 1.f : 2.f;
-                    pp = fmaf(wj * tr[u], cp[u].x, pp);
-                    qq = fmaf(wj * ti[u], cp[u].y, qq);
+                    const float a = wj * tr[u], b = wj * ti[u];
+#pragma unroll
+                    for (int lam = 0; lam < NLc; ++lam) { pp[lam] = fmaf(a, cp[u][lam].x, pp[lam]); qq[lam] = fmaf(b, cp[u][lam].y, qq[lam]); }
                 }
             }
         }
-        part[2 * it] = pp; part[2 * it + 1] = qq;
+#pragma unroll
+        for (int lam = 0; lam < NLc; ++lam) { part[(it * NLc + lam) * 2] = pp[lam]; part[(it * NLc + lam) * 2 + 1] = qq[lam]; }
     }
     __syncthreads();
     AEFFT_WGSTAMP(1, 3);
@@ -561,10 +574,10 @@ __device__ __forceinline__ void kgrad_sliced_body(const float2* __restrict__ D, 
         const int k = kl / NL, l = kl - k * NL;
         const int lam = l >= HL ? l - HL : HL - l;
         const float sg = l >= HL ? -1.f : 1.f;
-        const float* pt = part + 2 * ((p2 * TK + k * (HL + 1) + lam) * JS);
+        const float* pt = part + ((p2 * NK + k) * JS * NLc + lam) * 2;
         float a = 0.f;
 #pragma unroll 4
-        for (int js = 0; js < JS; ++js) a += pt[2 * js] + sg * pt[2 * js + 1];
+        for (int js = 0; js < JS; ++js) a += pt[js * NLc * 2] + sg * pt[js * NLc * 2 + 1];
         g[(pln * nchunks + chunk) * TT + kl] = a * scale;       // [plane][chunk][tap]: the consumer adds the chunks in order
     }
 }
@@ -722,16 +735,22 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
 {
     int total = 0; size_t lds = 0;
     for (int p = 0; p < g.n; ++p) { const int Nyr = g.q[p].Ny / 2 + 1; g.ppb[p] = std::max(1, 256 / Nyr); }
+#ifndef AEFFT_X_GROWS
+#define AEFFT_X_GROWS 64
+#endif
+    int extra = 0;                                          // trailing workgroups: the bin-major copy (kspec_packed_body)
+    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); }
+    long wg64 = extra;                                      // workgroups of the launch with 64-row chunks everywhere (G' tiles counted at one plane each: an upper bound)
+    for (int p = 0; p < g.n; ++p) wg64 += (g.gsrc[p].f ? (long)g.gsrc[p].dD * g.gsrc[p].dD : (g.q[p].planes + g.ppb[p] - 1) / g.ppb[p]) * ((g.q[p].Nx + 63) / 64);
+    const int grows = wg64 < 512 ? 16 : AEFFT_X_GROWS;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         // <= 64 rows per workgroup for every problem (a launch-wide chunk count gave the big grids 128-row workgroups on half their
         // lanes: 23.7 us against 21.5 us at cfg3; 32 rows: 22.0, 16 rows: 24.9)
-        // (G' problems with 32-row chunks -- their workgroups stand behind a tap-product stage and are the launch's long pole --: each is 2-3 us
-        // shorter, but there are twice as many for the same 768 resident slots: 18.8-19.1 vs 18.7-18.9 us for the launch, step +2 us.  64 for all.)
-#ifndef AEFFT_X_GROWS
-#define AEFFT_X_GROWS 64
-#endif
-        const int rmax = g.gsrc[p].f ? AEFFT_X_GROWS : 64;
+        // (G' problems -- their workgroups stand behind a tap-product stage and are the launch's long pole -- with 32-row chunks are each 2-3 us
+        // shorter, but twice as many for the launch's resident slots: 18.8-19.1 vs 18.7-18.9 us at cfg3, step +2 us.  So: 64 rows, and 16 in a launch
+        // that leaves most of the chip idle anyway (cfg2: 22 such workgroups): grows)
+        const int rmax = g.gsrc[p].f ? grows : 64;
         const int chunks = (q.Nx + rmax - 1) / rmax;
         g.rows[p] = (q.Nx + chunks - 1) / chunks;
         if (g.gsrc[p].f) {
@@ -763,8 +782,7 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     int threads = 256;                                    // one thread per (plane in group, column)
     for (int p = 0; p < g.n; ++p) threads = std::max(threads, ((g.ppb[p] * (g.q[p].Ny / 2 + 1) + 63) / 64) * 64);
     if (threads > 320) return hipErrorInvalidValue;
-    int extra = 0;
-    if (pk && pk->Wp && pk->Nk == NK && NK == NL) { pack_blocks(*pk); extra = pk->nblk * pack_yblocks(*pk); lds = std::max(lds, kspec_packed_lds(NK)); }
+    if (extra) lds = std::max(lds, kspec_packed_lds(NK));
     const int nb = bu ? bu->n : 0;
     kspec_group_kernel<NK, NL><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
     return hipGetLastError();
@@ -817,7 +835,7 @@ template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, cons
         const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::min(launch_cap, std::max(1, g.chunks[p])));     // in: room at dst; out: chunks used
         g.ppb[p] = k.ppb; g.rows[p] = k.S; g.rb[p] = k.RB; g.chunks[p] = k.chunks; g.pblocks[p] = k.pblocks;
         g.start[p] = total; total += k.pblocks * k.chunks;
-        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)std::max(NT, k.ppb * NK * NL)));
+        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)(NL / 2 + 1) * std::max(NT, k.ppb * NK)));      // (part: [tasks x column slices <= max(NT, tasks)][NL/2+1][2])
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
