@@ -28,6 +28,7 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
 // opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
 // A[OPIN_COLS-1][d][t] + sum_{j<D0} A[j][d][t] * Xf[b][j][u(t)], A [OPIN_COLS][D0][Nxi*(Nyi/2+1)], Xf [B][D0][Nx0*(Ny0/2+1)]
 constexpr int OPIN_COLS = 4;
+constexpr int OPMSE_PACKED_STEPS = 16;  // steps of the innermost pair's two stages in the post-update MSE (opmse_packed)
 constexpr int CH_MAXSTEPS = 40;       // most steps of a per-bin chain item (chain_geometry's table; cfg5: 26)
 constexpr int CH_VMAX = 128;          // most rows of a matrix the packed-record kernels (chain, innermost-pair MSE) take
 struct OpIn { const float2* A; const float2* Xf; int D0, Nx0, Ny0; };
@@ -205,7 +206,8 @@ struct OpMsePair {
     float scale;               // 1 / (2 dM Nx Ny B) / (dD Nx Ny)
 };
 struct OpMseGroup { OpMsePair q[8]; int n; int start[9], bt[8], base; const float2* Mhat; int Nx0, Ny0; long P0;
-                    const float2* Wp; int E, offC, offF; /* nullable: bin-major record of the UPDATED spectra; offsets of the innermost pair's C, F in it */ };
+                    const float2* Wp; int E, offC, offF; /* nullable: bin-major record of the UPDATED spectra; offsets of the innermost pair's C, F in it */
+                    unsigned pst_off[OPMSE_PACKED_STEPS], pst_desc[OPMSE_PACKED_STEPS]; int pst_n; /* (filled by the launcher) that pair's two stages as a step list */ };
 struct ChainArgs;
 struct UpdateGroup;
 // the MSE of every pair; optionally in the same launch: the operator chain of the NEXT step (chain, reading the just-written Wp / Cc, writing its own

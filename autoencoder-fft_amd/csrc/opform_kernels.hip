@@ -719,31 +719,236 @@ __device__ __forceinline__ void opmse_small_body(const OpMseGroup& g, int p, flo
     }
 }
 
+// ---- the per-bin item as a software pipeline over its record ----
+// The item's 2L stages are small dependent products whose matrices do NOT depend on the running vector: only the multiply waits for the
+// previous stage.  One output per thread and groups of 16 loads (chain_stage_rec) made every stage one to four memory round trips of its
+// own -- 24 us per item at cfg3, the long pole of the tail launch.  Here a STEP is up to CH_NE elements per thread of one stage's matrix,
+// thread <-> (row r, lane ks of KS <= 16 adjacent lanes: k = k0 + ks + KS u), every element of the record is loaded exactly once, and the loads
+// of step i + CH_DEPTH are issued before step i is computed: after the first round trip the stages run out of registers and LDS.  A stage
+// whose K range exceeds CH_NE * KS takes several steps (the row sums stay in registers); the KS partial sums of a row meet by lane exchange.
+// What keeps the pipeline a pipeline (hipcc's s_waitcnt insertion): every load is unconditional (clamped addresses, masked in the product;
+// the bias element rides along whether the item is the DC bin or not), so the number of loads in flight at each wait is static; the running
+// vectors are addressed off ONE LDS base (a select between two pointers turns the reads into flat loads, which wait for everything).
+// The step list is built by the host (chain_geometry).
+#ifndef AEFFT_X_CHAINPIPE
+#define AEFFT_X_CHAINPIPE 1
+#endif
+#ifndef AEFFT_X_CH_DEPTH
+#define AEFFT_X_CH_DEPTH 4
+#endif
+// acc += a * b as two v_pk_fma_f32 (the four FMAs of cfma2 in the same order per component: the same bits).  The steps below are bound by
+// their instruction count, not by latency -- where the latter holds (the stage-by-stage bodies) the packed form measured slower, DESIGN.md 6.
+#ifndef AEFFT_X_CH_PK
+#define AEFFT_X_CH_PK 1
+#endif
+__device__ __forceinline__ void cfma_pk(float2& acc, float2 a, float2 b)
+{
+#if AEFFT_X_CH_PK
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f r = {acc.x, acc.y};
+    const v2f av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(r) : "v"(av), "v"(bv));                          // + (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(av), "v"(bv));         // + (-a.y b.y, a.y b.x)
+    acc = make_float2(r.x, r.y);
+#else
+    cfma2(acc, a, b);
+#endif
+}
+constexpr int CH_NE = 4, CH_DEPTH = AEFFT_X_CH_DEPTH, CH_NB = CH_DEPTH + 1, CH_KSH_MAX = 4, CH_BLOCK = 12;
+// lane i <- lane i + N of the same 16-lane row (0 past the row's end)
+template <int N> __device__ __forceinline__ float dpp_row_shl(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+// desc: R (8 bits) | K (8) | k0 (7) | log2 KS (3) | last chunk of its stage | first chunk | encoder stage | level (3);  off: record offset of
+// the stage (24 bits) | bit 31: which of the two running vectors the stage reads
+// (SRC: what hosts the step list -- ChainSrc for the chain's items, PackedMseSrc for the innermost pair's post-update MSE)
+struct ChainSrc {
+    const ChainArgs& g;
+    __device__ __forceinline__ unsigned off(int i) const { return g.st_off[i]; }
+    __device__ __forceinline__ unsigned desc(int i) const { return g.st_desc[i]; }
+    __device__ __forceinline__ const float* bias(unsigned lv, bool enc) const { return enc ? g.lv[lv].b : g.lv[lv].p; }
+    __device__ __forceinline__ float NN(unsigned lv) const { return (float)g.lv[lv].Nx * (float)g.lv[lv].Ny; }
+    __device__ __forceinline__ float2* out(unsigned lv) const { return g.lv[lv].O; }        // a decoder stage's rows: O_l[c][r] at bin t of the support
+    __device__ __forceinline__ unsigned Pc() const { return (unsigned)g.Pc; }
+};
+template <class SRC>
+__device__ __forceinline__ void chain_step_load(const SRC& g, const float2* __restrict__ rec, const int i, float2 (&w)[CH_NE], float& bv)
+{
+    const unsigned d = g.desc(i), off = g.off(i) & 0xffffffu;
+    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
+    const unsigned tid = threadIdx.x;
+    const unsigned r = min(tid >> ksh, R - 1u), ks = tid & ((1u << ksh) - 1u);
+    const unsigned row = off + r * K, e0 = row + k0 + ks, elast = row + K - 1u;
+#pragma unroll
+    for (int u = 0; u < CH_NE; ++u) w[u] = ld8(rec, min(e0 + ((unsigned)u << ksh), elast));
+    bv = g.bias(d >> 29, (d >> 28) & 1u)[r];
+}
+template <class SRC>
+__device__ __forceinline__ void chain_step_compute(const SRC& g, const int i, const float2 (&w)[CH_NE], const float bv, float2 (&acc)[OPC], float2* const Wl, const int t)
+{
+    static_assert(OPC == 4, "two 16-byte LDS accesses per row of V");
+    const unsigned d = g.desc(i), par = g.off(i) >> 31;
+    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
+    const unsigned tid = threadIdx.x;
+    const unsigned rr = tid >> ksh, ks = tid & ((1u << ksh) - 1u);
+    const bool valid = rr < R;
+    if ((d >> 27) & 1u) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
+    }
+    const float2* Vin = Wl + par * (CH_VMAX * OPC);
+#pragma unroll
+    for (int u = 0; u < CH_NE; ++u) {
+        const unsigned k = k0 + ks + ((unsigned)u << ksh);
+        const bool ok = valid && k < K;
+        const float2 wv = ok ? w[u] : make_float2(0.f, 0.f);
+        const float4* vp = reinterpret_cast<const float4*>(Vin + min(k, K - 1u) * OPC);
+        const float4 va = vp[0], vb = vp[1];
+        cfma_pk(acc[0], wv, make_float2(va.x, va.y)); cfma_pk(acc[1], wv, make_float2(va.z, va.w));
+        cfma_pk(acc[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc[3], wv, make_float2(vb.z, vb.w));
+    }
+    if (!((d >> 26) & 1u)) return;                                // (uniform) more chunks of this stage follow
+    // the KS <= 16 lanes of a row are adjacent and aligned inside a 16-lane DPP row: lane i += lane i + 2^j (row_shl, one v_add_f32_dpp each; lanes
+    // shifted in from outside the row read 0) leaves the row's sum in its lane ks == 0 -- the only one that stores.  (__shfl_xor is a
+    // ds_bpermute with its own wait per value: 48 of them per stage were 1.3 us of every stage.)
+    if (ksh > 0) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<1>(acc[c].x); acc[c].y += dpp_row_shl<1>(acc[c].y); }
+    }
+    if (ksh > 1) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<2>(acc[c].x); acc[c].y += dpp_row_shl<2>(acc[c].y); }
+    }
+    if (ksh > 2) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<4>(acc[c].x); acc[c].y += dpp_row_shl<4>(acc[c].y); }
+    }
+    if (ksh > 3) {
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<8>(acc[c].x); acc[c].y += dpp_row_shl<8>(acc[c].y); }
+    }
+    const bool enc = (d >> 28) & 1u;
+    const unsigned lv = d >> 29;
+    if (valid && ks == 0) {
+        const float scale = __frcp_rn((float)R);
+#pragma unroll
+        for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
+        if (t == 0) acc[OPC - 1].x += bv * g.NN(lv);
+        const float4 o0 = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), o1 = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+        float4* vo = reinterpret_cast<float4*>(Wl + (par ^ 1u) * (CH_VMAX * OPC) + rr * OPC);
+        vo[0] = o0; vo[1] = o1;
+        if (!enc) {                                               // (uniform) a decoder stage: its rows may be an output of the item
+            float2* O = g.out(lv);
+            if (O) {
+                const unsigned Pc = g.Pc();
+#pragma unroll
+                for (int c = 0; c < OPC; ++c) st8(O, ((unsigned)c * R + rr) * Pc + (unsigned)t, acc[c]);
+            }
+        }
+    }
+    __syncthreads();                                              // (uniform branch: every thread of the workgroup is here) the stage's output is complete
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(Wl + 3 * CH_VMAX * OPC + 4 + OPC * OPC)[(enc ? lv : 7 - lv) & 7] = wall_clock64();    // (in LDS: a global store here would drain the pipeline it times)
+#endif
+}
+// straight-line code, one copy per step, the exits nested (a template recursion): with a LOOP around the rotation hipcc's wait insertion merges
+// the loop's entry and back edge into a vmcnt(0) at the header -- a drained pipeline every CH_NB steps -- and a rolled loop would index the
+// register sets dynamically (scratch)
+template <int I, class SRC>
+__device__ __forceinline__ void chain_steps(const SRC& g, const float2* __restrict__ rec, const int base, const int nb, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
+                                            float2 (&acc)[OPC], float2* const Wl, const int t)
+{
+    if constexpr (I < CH_BLOCK) {
+        if (I >= nb) return;                                      // (uniform)
+        chain_step_load(g, rec, base + min(I + CH_DEPTH, nb - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
+        chain_step_compute(g, base + I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
+        chain_steps<I + 1, SRC>(g, rec, base, nb, w, bv, acc, Wl, t);
+    }
+}
+// every step of a list: blocks of CH_BLOCK straight-line steps (cfg3: one block); the pipeline drains and refills between blocks.  `init`: fills the
+// first running vector (buffer 0 of Wl) while the first loads are in flight; the barrier behind it is this function's.
+template <class SRC, class INIT>
+__device__ __forceinline__ void chain_run_steps(const SRC& g, const float2* __restrict__ rec, const int n, float2* const Wl, const int t, INIT init)
+{
+    float2 w[CH_NB][CH_NE];
+    float bv[CH_NB];
+    float2 acc[OPC];
+    for (int base = 0; base < n; base += CH_BLOCK) {
+        const int nb = min(n - base, CH_BLOCK);
+#pragma unroll
+        for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, base + min(j, nb - 1), w[j], bv[j]);
+        if (base == 0) { init(); __syncthreads(); }
+        chain_steps<0, SRC>(g, rec, base, nb, w, bv, acc, Wl, t);
+    }
+}
+// host: the steps of one stage (R x K matrix at record offset `off`, reading running vector `par`) appended to a step list; false: the list is full
+static bool chain_add_stage(unsigned* st_off, unsigned* st_desc, int* n, int cap, int R, int K, unsigned off, int par, bool enc, int lvl)
+{
+    int ksh = 0;                                                     // KS = min(largest power of two <= 256 / R, smallest power of two >= K, 16)
+    while (ksh < CH_KSH_MAX && (2 << ksh) * R <= 256 && (1 << ksh) < K) ++ksh;
+    const int kc = CH_NE << ksh;
+    for (int k0 = 0; k0 < K; k0 += kc) {
+        if (*n >= cap || off >= (1u << 24) || k0 > 127 || R > 255 || K > 255) return false;
+        st_off[*n] = off | ((unsigned)(par & 1) << 31);
+        st_desc[*n] = (unsigned)R | ((unsigned)K << 8) | ((unsigned)k0 << 16) | ((unsigned)ksh << 23) | ((k0 + kc >= K ? 1u : 0u) << 26) |
+                      ((k0 == 0 ? 1u : 0u) << 27) | ((enc ? 1u : 0u) << 28) | ((unsigned)lvl << 29);
+        ++*n;
+    }
+    return true;
+}
+
 // The innermost pair from the bin-major copy of the updated spectra (kspec_packed_body): one workgroup per bin, C' and F' read as
 // contiguous rows (the planar layout makes them 8 K scattered 32-byte pieces per bin tile), two chain stages and the quadratic form.
-constexpr size_t OPMSE_PACKED_LDS = sizeof(float2) * (3 * CH_VMAX * OPC + 2);
+constexpr size_t OPMSE_PACKED_LDS = sizeof(float2) * (3 * CH_VMAX * OPC + 2 + OPC * OPC) + 128;
+struct PackedMseSrc {                                   // the two stages C', F' of the innermost pair as a step list (chain_run_steps)
+    const OpMseGroup& g; const OpMsePair& q;
+    __device__ __forceinline__ unsigned off(int i) const { return g.pst_off[i]; }
+    __device__ __forceinline__ unsigned desc(int i) const { return g.pst_desc[i]; }
+    __device__ __forceinline__ const float* bias(unsigned, bool enc) const { return enc ? q.b : q.p; }
+    __device__ __forceinline__ float NN(unsigned) const { return (float)q.Nx * (float)q.Ny; }
+    __device__ __forceinline__ float2* out(unsigned) const { return nullptr; }
+    __device__ __forceinline__ unsigned Pc() const { return 0u; }
+};
 __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t, float2* sh)
 {
-    float2 *Va = sh, *Vb = sh + CH_VMAX * OPC, *Vc = sh + 2 * CH_VMAX * OPC;
+    float2 *Va = sh + 2 * CH_VMAX * OPC;                 // A of the bin (kept); the running vectors are buffers 0 and 1 of sh
     float* redp = reinterpret_cast<float*>(sh + 3 * CH_VMAX * OPC);
     const OpMsePair q = g.q[p];
     const int dD = q.dD, dM = q.dM;
-    for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; Va[i] = q.A[((long)k * dD + a) * q.P + t]; }
     const float2* rec = g.Wp + t * g.E;
-    const float NN = (float)q.Nx * (float)q.Ny;
-    __syncthreads();
-    chain_stage_rec(rec + g.offC, Va, Vb, dM, dD, 1.0f / (float)dM, q.b, NN, t == 0, nullptr, 0, 0);
-    __syncthreads();
-    chain_stage_rec(rec + g.offF, Vb, Vc, dD, dM, 1.0f / (float)dD, q.p, NN, t == 0, nullptr, 0, 0);
-    __syncthreads();
+    const float2* Vc;                                    // F'(C' A / dM + b^) / dD + p^ of the bin
+    float2* Ms = sh + 3 * CH_VMAX * OPC + 2;             // the bin's 4x4 moments, requested with A (behind the stages they were a round trip of their own)
+    const long um = map_up(t, q.Nx, q.Ny, g.Nx0, g.Ny0);
+    if (g.pst_n > 0) {
+        // (as a software pipeline over the record: the stage-by-stage form below was six dependent round trips, 11 us per workgroup at cfg3)
+        const PackedMseSrc src{g, q};
+        chain_run_steps(src, rec, g.pst_n, sh, (int)t, [&]() {
+            float2 mv = make_float2(0.f, 0.f);
+            if (threadIdx.x < OPC * OPC) mv = g.Mhat[(long)threadIdx.x * g.P0 + um];
+            for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; const float2 v = q.A[((long)k * dD + a) * q.P + t]; sh[i] = v; Va[i] = v; }
+            if (threadIdx.x < OPC * OPC) Ms[threadIdx.x] = mv;
+        });
+        Vc = sh;                                         // (stage 0 reads buffer 0 and writes 1, stage 1 writes 0; its barrier has been passed)
+    } else {
+        float2 *Vb = sh, *Vd = sh + CH_VMAX * OPC;
+        if (threadIdx.x < OPC * OPC) Ms[threadIdx.x] = g.Mhat[(long)threadIdx.x * g.P0 + um];
+        for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; Va[i] = q.A[((long)k * dD + a) * q.P + t]; }
+        const float NN = (float)q.Nx * (float)q.Ny;
+        __syncthreads();
+        chain_stage_rec(rec + g.offC, Va, Vb, dM, dD, 1.0f / (float)dM, q.b, NN, t == 0, nullptr, 0, 0);
+        __syncthreads();
+        chain_stage_rec(rec + g.offF, Vb, Vd, dD, dM, 1.0f / (float)dD, q.p, NN, t == 0, nullptr, 0, 0);
+        __syncthreads();
+        Vc = Vd;
+    }
     float part = 0.f;
     if ((int)threadIdx.x < dD) {
         const int a = threadIdx.x;
-        const long u = map_up(t, q.Nx, q.Ny, g.Nx0, g.Ny0);
         float2 r[OPC];
 #pragma unroll
         for (int k = 0; k < OPC; ++k) { const float2 av = Va[a * OPC + k], fv = Vc[a * OPC + k]; r[k] = make_float2(av.x - fv.x, av.y - fv.y); }
-        part = quad_centred(r, [&](int e) { return g.Mhat[(long)e * g.P0 + u]; });
+        part = quad_centred(r, [&](int e) { return Ms[e]; });
         const int nyr = q.Ny / 2 + 1;
         const int j = (int)((unsigned)t % (unsigned)nyr);
         part *= (j > 0 && j < nyr - 1) ? 2.f : 1.f;
@@ -793,7 +998,13 @@ static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t*
         while (bt > 4 && ((q.P + bt - 1) / bt < 128 || (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) > 48 * 1024)) bt >>= 1;
         size_t need = (size_t)OPC * (q.dD + q.dM) * bt * sizeof(float2) + 64 + (size_t)256 * OPC * sizeof(float2) + (size_t)OPC * OPC * bt * sizeof(float2);
         const bool pk = i == g.n - 1 && g.Wp && q.dD <= CH_VMAX && q.dM <= CH_VMAX;
-        if (pk) need = OPMSE_PACKED_LDS;
+        if (pk) {
+            need = OPMSE_PACKED_LDS;
+            int n = 0;
+            const bool fits = chain_add_stage(g.pst_off, g.pst_desc, &n, OPMSE_PACKED_STEPS, q.dM, q.dD, (unsigned)g.offC, 0, true, 0) &&
+                              chain_add_stage(g.pst_off, g.pst_desc, &n, OPMSE_PACKED_STEPS, q.dD, q.dM, (unsigned)g.offF, 1, false, 0);
+            g.pst_n = fits && AEFFT_X_CHAINPIPE ? n : 0;
+        }
         else if (q.G) {                                                  // opmse_gbody
             if ((double)q.dD * q.dD * q.P * 8.0 >= 4294967296.0) return hipErrorInvalidValue;
             bt = msgrad_bt(q.dD, q.P);
@@ -863,162 +1074,15 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 //  * the rest: a tile of CH_BT consecutive bins of grid j (1 <= j < L), threads = (bin, row group).  It recomputes the tile's
 //    ancestor chain A_1 .. A_j from the PLANAR spectra (small matrices; lanes along the bins: coalesced) and stores A_j.
 // No workgroup waits for another one; the only cost of the independence is the re-evaluation of a few small products.
-// ---- the per-bin item as a software pipeline over its record ----
-// The item's 2L stages are small dependent products whose matrices do NOT depend on the running vector: only the multiply waits for the
-// previous stage.  One output per thread and groups of 16 loads (chain_stage_rec) made every stage one to four memory round trips of its
-// own -- 24 us per item at cfg3, the long pole of the tail launch.  Here a STEP is up to CH_NE elements per thread of one stage's matrix,
-// thread <-> (row r, lane ks of KS <= 16 adjacent lanes: k = k0 + ks + KS u), every element of the record is loaded exactly once, and the loads
-// of step i + CH_DEPTH are issued before step i is computed: after the first round trip the stages run out of registers and LDS.  A stage
-// whose K range exceeds CH_NE * KS takes several steps (the row sums stay in registers); the KS partial sums of a row meet by lane exchange.
-// What keeps the pipeline a pipeline (hipcc's s_waitcnt insertion): every load is unconditional (clamped addresses, masked in the product;
-// the bias element rides along whether the item is the DC bin or not), so the number of loads in flight at each wait is static; the running
-// vectors are addressed off ONE LDS base (a select between two pointers turns the reads into flat loads, which wait for everything).
-// The step list is built by the host (chain_geometry).
-#ifndef AEFFT_X_CHAINPIPE
-#define AEFFT_X_CHAINPIPE 1
-#endif
-#ifndef AEFFT_X_CH_DEPTH
-#define AEFFT_X_CH_DEPTH 4
-#endif
-// acc += a * b as two v_pk_fma_f32 (the four FMAs of cfma2 in the same order per component: the same bits).  The steps below are bound by
-// their instruction count, not by latency -- where the latter holds (the stage-by-stage bodies) the packed form measured slower, DESIGN.md 6.
-#ifndef AEFFT_X_CH_PK
-#define AEFFT_X_CH_PK 1
-#endif
-__device__ __forceinline__ void cfma_pk(float2& acc, float2 a, float2 b)
-{
-#if AEFFT_X_CH_PK
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f r = {acc.x, acc.y};
-    const v2f av = {a.x, a.y}, bv = {b.x, b.y};
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(r) : "v"(av), "v"(bv));                          // + (a.x b.x, a.x b.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(av), "v"(bv));         // + (-a.y b.y, a.y b.x)
-    acc = make_float2(r.x, r.y);
-#else
-    cfma2(acc, a, b);
-#endif
-}
-constexpr int CH_NE = 4, CH_DEPTH = AEFFT_X_CH_DEPTH, CH_NB = CH_DEPTH + 1, CH_KSH_MAX = 4, CH_BLOCK = 12;
-// lane i <- lane i + N of the same 16-lane row (0 past the row's end)
-template <int N> __device__ __forceinline__ float dpp_row_shl(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
-}
-// desc: R (8 bits) | K (8) | k0 (7) | log2 KS (3) | last chunk of its stage | first chunk | encoder stage | level (3);  off: record offset of
-// the stage (24 bits) | bit 31: which of the two running vectors the stage reads
-__device__ __forceinline__ void chain_step_load(const ChainArgs& g, const float2* __restrict__ rec, const int i, float2 (&w)[CH_NE], float& bv)
-{
-    const unsigned d = g.st_desc[i], off = g.st_off[i] & 0xffffffu;
-    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
-    const unsigned tid = threadIdx.x;
-    const unsigned r = min(tid >> ksh, R - 1u), ks = tid & ((1u << ksh) - 1u);
-    const unsigned row = off + r * K, e0 = row + k0 + ks, elast = row + K - 1u;
-#pragma unroll
-    for (int u = 0; u < CH_NE; ++u) w[u] = ld8(rec, min(e0 + ((unsigned)u << ksh), elast));
-    const ChainLevel& lvl = g.lv[d >> 29];
-    const float* bias = (d >> 28) & 1u ? lvl.b : lvl.p;
-    bv = bias[r];
-}
-__device__ __forceinline__ void chain_step_compute(const ChainArgs& g, const int i, const float2 (&w)[CH_NE], const float bv, float2 (&acc)[OPC], float2* const Wl, const int t)
-{
-    static_assert(OPC == 4, "two 16-byte LDS accesses per row of V");
-    const unsigned d = g.st_desc[i], par = g.st_off[i] >> 31;
-    const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
-    const unsigned tid = threadIdx.x;
-    const unsigned rr = tid >> ksh, ks = tid & ((1u << ksh) - 1u);
-    const bool valid = rr < R;
-    if ((d >> 27) & 1u) {
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
-    }
-    const float2* Vin = Wl + par * (CH_VMAX * OPC);
-#pragma unroll
-    for (int u = 0; u < CH_NE; ++u) {
-        const unsigned k = k0 + ks + ((unsigned)u << ksh);
-        const bool ok = valid && k < K;
-        const float2 wv = ok ? w[u] : make_float2(0.f, 0.f);
-        const float4* vp = reinterpret_cast<const float4*>(Vin + min(k, K - 1u) * OPC);
-        const float4 va = vp[0], vb = vp[1];
-        cfma_pk(acc[0], wv, make_float2(va.x, va.y)); cfma_pk(acc[1], wv, make_float2(va.z, va.w));
-        cfma_pk(acc[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc[3], wv, make_float2(vb.z, vb.w));
-    }
-    if (!((d >> 26) & 1u)) return;                                // (uniform) more chunks of this stage follow
-    // the KS <= 16 lanes of a row are adjacent and aligned inside a 16-lane DPP row: lane i += lane i + 2^j (row_shl, one v_add_f32_dpp each; lanes
-    // shifted in from outside the row read 0) leaves the row's sum in its lane ks == 0 -- the only one that stores.  (__shfl_xor is a
-    // ds_bpermute with its own wait per value: 48 of them per stage were 1.3 us of every stage.)
-    if (ksh > 0) {
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<1>(acc[c].x); acc[c].y += dpp_row_shl<1>(acc[c].y); }
-    }
-    if (ksh > 1) {
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<2>(acc[c].x); acc[c].y += dpp_row_shl<2>(acc[c].y); }
-    }
-    if (ksh > 2) {
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<4>(acc[c].x); acc[c].y += dpp_row_shl<4>(acc[c].y); }
-    }
-    if (ksh > 3) {
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<8>(acc[c].x); acc[c].y += dpp_row_shl<8>(acc[c].y); }
-    }
-    const bool enc = (d >> 28) & 1u;
-    const unsigned lv = d >> 29;
-    if (valid && ks == 0) {
-        const float scale = __frcp_rn((float)R);
-#pragma unroll
-        for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
-        if (t == 0) acc[OPC - 1].x += bv * ((float)g.lv[lv].Nx * (float)g.lv[lv].Ny);
-        const float4 o0 = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), o1 = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
-        float4* vo = reinterpret_cast<float4*>(Wl + (par ^ 1u) * (CH_VMAX * OPC) + rr * OPC);
-        vo[0] = o0; vo[1] = o1;
-        if (!enc) {                                               // (uniform) a decoder stage: its rows are an output of the item, O_l[c][r] at bin t of the support
-            float2* O = g.lv[lv].O;
-            const unsigned Pc = (unsigned)g.Pc;
-#pragma unroll
-            for (int c = 0; c < OPC; ++c) st8(O, ((unsigned)c * R + rr) * Pc + (unsigned)t, acc[c]);
-        }
-    }
-    __syncthreads();                                              // (uniform branch: every thread of the workgroup is here) the stage's output is complete
-#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(Wl + 2 * CH_VMAX * OPC)[(enc ? lv : 2 * g.L - 1 - lv) & 7] = wall_clock64();    // (in LDS: a global store here would drain the pipeline it times)
-#endif
-}
-// straight-line code, one copy per step, the exits nested (a template recursion): with a LOOP around the rotation hipcc's wait insertion merges
-// the loop's entry and back edge into a vmcnt(0) at the header -- a drained pipeline every CH_NB steps -- and a rolled loop would index the
-// register sets dynamically (scratch)
-template <int I>
-__device__ __forceinline__ void chain_steps(const ChainArgs& g, const float2* __restrict__ rec, const int base, const int nb, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
-                                            float2 (&acc)[OPC], float2* const Wl, const int t)
-{
-    if constexpr (I < CH_BLOCK) {
-        if (I >= nb) return;                                      // (uniform)
-        chain_step_load(g, rec, base + min(I + CH_DEPTH, nb - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
-        chain_step_compute(g, base + I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
-        chain_steps<I + 1>(g, rec, base, nb, w, bv, acc, Wl, t);
-    }
-}
 __device__ __forceinline__ void chain_item_pipelined(const ChainArgs& g, const int t, float2* Wl)
 {
-    const float2* rec = g.Wp + (long)t * g.E;
-    const int n = g.st_n;
-    float2 w[CH_NB][CH_NE];
-    float bv[CH_NB];
-    float2 acc[OPC];
-    // blocks of CH_BLOCK straight-line steps (cfg3: one block); the pipeline drains and refills between blocks
-    for (int base = 0; base < n; base += CH_BLOCK) {
-        const int nb = min(n - base, CH_BLOCK);
-#pragma unroll
-        for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, base + min(j, nb - 1), w[j], bv[j]);
-        if (base == 0) {
-            for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
-            __syncthreads();
-        }
-        chain_steps<0>(g, rec, base, nb, w, bv, acc, Wl, t);
-    }
+    const ChainSrc src{g};
+    chain_run_steps(src, g.Wp + (long)t * g.E, g.st_n, Wl, t, [&]() {
+        for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+    });
 #if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
     if (threadIdx.x == 0 && g_wgtime && blockIdx.x < WGT_MAX)
-        for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 2 * CH_VMAX * OPC)[k];
+        for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 3 * CH_VMAX * OPC + 4 + OPC * OPC)[k];
 #endif
 }
 
@@ -1126,24 +1190,15 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     {
         // the per-bin item's step list (chain_item_pipelined): stage si = level si's encoder matrix, then the decoders from the innermost level out
         int n = 0; unsigned off = 0;
-        for (int si = 0; si < 2 * g.L; ++si) {
+        bool fits = true;
+        for (int si = 0; si < 2 * g.L && fits; ++si) {
             const bool enc = si < g.L;
             const int l = enc ? si : 2 * g.L - 1 - si;
             const int R = enc ? g.lv[l].dM : g.lv[l].dD, K = enc ? g.lv[l].dD : g.lv[l].dM;
-            int ksh = 0;                                             // KS = min(largest power of two <= 256 / R, smallest power of two >= K, 16)
-            while (ksh < CH_KSH_MAX && (2 << ksh) * R <= 256 && (1 << ksh) < K) ++ksh;
-            const int kc = CH_NE << ksh;
-            for (int k0 = 0; k0 < K; k0 += kc) {
-                if (off >= (1u << 24) || k0 > 127) return hipErrorInvalidValue;
-                if (n >= CH_MAXSTEPS) { ++n; continue; }             // (counted only: the item then runs stage by stage, chain_stage_rec)
-                g.st_off[n] = off | ((unsigned)(si & 1) << 31);
-                g.st_desc[n] = (unsigned)R | ((unsigned)K << 8) | ((unsigned)k0 << 16) | ((unsigned)ksh << 23) | ((k0 + kc >= K ? 1u : 0u) << 26) |
-                               ((k0 == 0 ? 1u : 0u) << 27) | ((enc ? 1u : 0u) << 28) | ((unsigned)l << 29);
-                ++n;
-            }
+            fits = chain_add_stage(g.st_off, g.st_desc, &n, CH_MAXSTEPS, R, K, off, si & 1, enc, l);
             off += (unsigned)((R * K + 1) & ~1);
         }
-        g.st_n = n <= CH_MAXSTEPS ? n : 0;
+        g.st_n = fits ? n : 0;                                          // (0: the item runs stage by stage, chain_stage_rec)
         if ((double)4 * CH_VMAX * (double)g.Pc >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit element offsets of the output stores)
     }
     long total = g.Pc;
@@ -1154,7 +1209,7 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
     g.vt_elems = rmax * OPC * CH_BT;
     *nblocks = total;
-    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS + 64 /* (experiment builds: stage stamps) */);
+    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS + sizeof(float2) * CH_VMAX * OPC + 256 /* (experiment builds: stage stamps behind a third vector) */);
     return hipSuccess;
 }
 
