@@ -82,6 +82,8 @@ SIGNATURES = {
     "aefft_magnitude": (_i, [_vp, _fp, _fp, _l, _i, _i, _i, _i]),
     "aefft_net_train_pair": (_i, [_vp, _i, _i, _f, _i, _i, _vp]),
     "aefft_net_step_grad": (_i, [_vp, _fp, _fp]),
+    "aefft_net_step_grad_u8": (_i, [_vp, _vp, _fp]),
+    "aefft_net_forward_u8": (_i, [_vp, _vp, _fp]),
     "aefft_net_set_input_ready": (_i, [_vp, _i]),
     "aefft_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "aefft_net_step_form": (_i, [_vp]),
@@ -159,6 +161,11 @@ def _ptr(t):
     if t is None:
         return None
     return C.c_void_p(t.data_ptr())
+
+
+def _is_u8(t):
+    import torch
+    return t is not None and t.dtype == torch.uint8
 
 
 def _hptr(a):
@@ -461,7 +468,8 @@ class Net:
         self.ctx.check(self.L.aefft_net_load_spectra(self.h, l, *[_hptr(v) for v in a]))
 
     def forward(self, frames, recon=None):
-        self.ctx.check(self.L.aefft_net_forward(self.h, _ptr(frames), _ptr(recon)))
+        fn = self.L.aefft_net_forward_u8 if _is_u8(frames) else self.L.aefft_net_forward
+        self.ctx.check(fn(self.h, _ptr(frames), _ptr(recon)))
         return recon
 
     def get_layer(self, layer):
@@ -495,7 +503,9 @@ class Net:
         self.ctx.check(self.L.aefft_net_set_input_ready(self.h, 1 if on else 0))
 
     def step_grad(self, frames, recon=None):
-        self.ctx.check(self.L.aefft_net_step_grad(self.h, _ptr(frames), _ptr(recon)))
+        """frames: float32 [B][D][Nx][Ny], or uint8 of the same shape (8-bit pixels: aefft_net_step_grad_u8, converted by the input transform)."""
+        fn = self.L.aefft_net_step_grad_u8 if _is_u8(frames) else self.L.aefft_net_step_grad
+        self.ctx.check(fn(self.h, _ptr(frames), _ptr(recon)))
 
     def grad_buffer(self):
         """torch view of the packed gradient buffer (for torch.distributed.all_reduce)."""

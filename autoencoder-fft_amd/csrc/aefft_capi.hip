@@ -31,6 +31,7 @@ struct aefft_ctx {
     hipStream_t stream = nullptr;    // the caller-visible stream: every public call is ordered on it
     hipStream_t cur = nullptr;       // stream the helpers enqueue on (== stream except inside a forked section)
     bool own_stream = false;
+    bool in_u8 = false;              // the frames handed to the running call are 8-bit pixels (aefft_net_step_grad_u8 / aefft_net_forward_u8: do_r2c converts on load)
     int biasColP1 = 0;               // operator form: conv_k biases go to the affine column of the basis frames only (Contract::biasColP1)
     bool recon_join = false;         // a deferred reconstruction (pipelined mode) still has to be joined from aux[0] (ev_join[0])
     static const int NAUX = 2;
@@ -354,9 +355,12 @@ static int do_c2r_any(aefft_ctx* ctx, const float2* X, float* x, long planes, in
 }
 
 // R2C (+ fused crop to Nxs x Nys).  The two kernels are bracketed separately for profiling.
+// (ctx->in_u8, set by aefft_net_step_grad_u8 for the duration of its call: x holds 8-bit pixels)
 static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx, int Ny, int Nxs, int Nys, int ws_id = WS_MID, hipEvent_t done = nullptr)
 {
+    const bool u8 = ctx->in_u8;
     if (!pow2_sizes(Nx, Ny) || !pow2_sizes(Nxs, Nys)) {
+        if (u8) return fail(ctx, AEFFT_EINVAL, "r2c: 8-bit frames need power-of-two sizes");
         RET_IF(chk_size_any(ctx, Nx, Ny));
         if (!aligned16(x) || !aligned16(X)) return fail(ctx, AEFFT_EINVAL, "r2c: pointers must be 16-byte aligned");
         return do_r2c_any(ctx, x, X, planes, Nx, Ny, Nxs, Nys);
@@ -367,12 +371,12 @@ static int do_r2c(aefft_ctx* ctx, const float* x, float2* X, long planes, int Nx
     RET_IF(ws_get(ctx, ws_id, sizeof(float2) * fft_mid_elems(planes, Nx, Nys / 2), &mid));
     // launch_r2c issues rows then cols; bracket as two launches by splitting the byte accounting:
     // rows: read planes*Nx*Ny*4, write mid; cols: read mid, write out.
-    const double b_in = (double)planes * Nx * Ny * 4, b_mid = (double)planes * Nx * (Nys / 2) * 8, b_out = (double)planes * bins(Nxs, Nys) * 8;
+    const double b_in = (double)planes * Nx * Ny * (u8 ? 1 : 4), b_mid = (double)planes * Nx * (Nys / 2) * 8, b_out = (double)planes * bins(Nxs, Nys) * 8;
     hipError_t e;
     {
         // The row and column kernels are launched inside launch_r2c; to time them separately we call it in two halves.
         Bracket br(ctx, KID_R2C_ROWS, b_in + b_mid);
-        e = launch_r2c(x, nullptr, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur);
+        e = launch_r2c(x, nullptr, (float2*)mid, planes, Nx, Ny, Nxs, Nys, ctx->cur, nullptr, u8);
     }
     if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "r2c rows", e);
     {
@@ -1089,6 +1093,7 @@ struct aefft_net {
     float* mse_dev = nullptr;  // scratch for bursts
     size_t mse_cap = 0;
     const float* last_frames = nullptr;
+    bool last_frames_u8 = false;     // ... and they were 8-bit pixels
     bool have_forward = false, have_grad = false;
     int NxC = 0, NyC = 0; long Pc = 0;   // grid of the coarsest pair = support of every decoder output
     bool compact = true;                 // the training step may keep decoder outputs on that support only
@@ -1746,7 +1751,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         if (async && n->input_ready && !flag(AEFFT_F_NODEFER)) {
             // pipelined loop (aefft_net_set_input_ready): launched by aefft_net_step_grad after the gradient half instead
             n->recon_deferred = recon_d;
-            n->last_frames = frames_d;
+            n->last_frames = frames_d; n->last_frames_u8 = ctx->in_u8;
             n->have_forward = true; n->have_grad = false;
             return AEFFT_OK;
         }
@@ -1763,7 +1768,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
         RET_IF(rc);
         n->recon_pending = async;
     }
-    n->last_frames = frames_d;
+    n->last_frames = frames_d; n->last_frames_u8 = ctx->in_u8;
     n->have_forward = true; n->have_grad = false;
     return AEFFT_OK;
 }
@@ -1799,8 +1804,11 @@ static int ensure_frames(aefft_net* n)
     if (!n->op_state) return AEFFT_OK;
     // (operator form without the chain launch: the activation buffers hold the operators themselves; the per-frame forward of the
     // same frames is run -- the caller's frame buffer must still hold them, include/aefft.h)
-    const bool hg = n->have_grad;
-    RET_IF(net_forward(n, n->last_frames, nullptr, false, false));
+    const bool hg = n->have_grad, u8 = n->ctx->in_u8;
+    n->ctx->in_u8 = n->last_frames_u8;
+    const int rcf = net_forward(n, n->last_frames, nullptr, false, false);
+    n->ctx->in_u8 = u8;
+    RET_IF(rcf);
     n->have_grad = hg;
     return AEFFT_OK;
 }
@@ -1865,6 +1873,11 @@ extern "C" int aefft_net_get_layer(aefft_net* n, int layer, float* out_d, int* c
     if (!out_d) return AEFFT_OK;
     if (!n->have_forward) return fail(ctx, AEFFT_ESTATE, "aefft_net_get_layer: no forward pass yet");
     if (layer == 0) {
+        if (n->last_frames_u8) {
+            hipError_t e = launch_u8_to_f32(out_d, reinterpret_cast<const unsigned char*>(n->last_frames), (long)B * c * x * y, ctx->stream);
+            if (e != hipSuccess) return fail(ctx, AEFFT_EHIP, "get_layer: 8-bit frames", e);
+            return AEFFT_OK;
+        }
         HIPCHK(ctx, hipMemcpyAsync(out_d, n->last_frames, sizeof(float) * B * c * x * y, hipMemcpyDeviceToDevice, ctx->stream));
         return AEFFT_OK;
     }
@@ -2536,6 +2549,24 @@ extern "C" int aefft_net_step_grad(aefft_net* n, const float* frames_d, float* r
     n->have_grad = true;
     if (n->input_ready && n->ev_mid) { HIPCHK(ctx, hipEventRecord(n->ev_mid, ctx->stream)); n->ev_mid_valid = true; }
     return mark_step_point(n);
+}
+
+// 8-bit frames: the same calls with the input transform converting on load (fft_kernels.hip r2c_rows_kernel<N, true>); nothing else reads the frames
+extern "C" int aefft_net_step_grad_u8(aefft_net* n, const unsigned char* frames_d, float* recon_d)
+{
+    if (!n) return AEFFT_EINVAL;
+    n->ctx->in_u8 = true;
+    const int rc = aefft_net_step_grad(n, reinterpret_cast<const float*>(frames_d), recon_d);
+    n->ctx->in_u8 = false;
+    return rc;
+}
+extern "C" int aefft_net_forward_u8(aefft_net* n, const unsigned char* frames_d, float* recon_d)
+{
+    if (!n) return AEFFT_EINVAL;
+    n->ctx->in_u8 = true;
+    const int rc = aefft_net_forward(n, reinterpret_cast<const float*>(frames_d), recon_d);
+    n->ctx->in_u8 = false;
+    return rc;
 }
 
 extern "C" int aefft_net_step_form(aefft_net* n)

@@ -238,8 +238,10 @@ template <int N> struct RowCfg {
     static constexpr int PL = pad_len(N);
 };
 
-template <int N>
-__global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __restrict__ in, float2* __restrict__ mid,
+// U8: the frames are 8-bit pixels (what a camera delivers; the reference's application converts them to floats on the host, netlib.cpp:37-51):
+// a quarter of the launch's reads, the conversion is exact (v_cvt_f32_ubyteN), everything behind the load is the float kernel.
+template <int N, bool U8>
+__global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const void* __restrict__ in_v, float2* __restrict__ mid,
                                                                    long npairs, int Wc)
 {
     using Cfg = RowCfg<N>;
@@ -256,16 +258,34 @@ __global__ __launch_bounds__(RowCfg<N>::NT) void r2c_rows_kernel(const float* __
     // a + i*b -- consecutive in the padded layout, i.e. two ds_write2_b64 -- instead of eight 4-byte halves at stride 2.
     constexpr int NPOS = G * (N / 4) / NT;                      // positions per thread (= 2 when NT = G*N/8)
     static_assert((G * (N / 4)) % NT == 0, "tile must be a whole number of positions per thread");
-    const float4* src = reinterpret_cast<const float4*>(in + pair0 * 2 * N);
     const int live = npairs - pair0 < G ? (int)(npairs - pair0) : G;      // row pairs of this workgroup that exist (uniform)
     float4 va[NPOS], vb[NPOS];
+    if constexpr (U8) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(in_v) + pair0 * 2 * N);      // four pixels per word
+        unsigned wa[NPOS], wb[NPOS];
 #pragma unroll
-    for (int q = 0; q < NPOS; ++q) {
-        const int pos = tid + q * NT;
-        const int gg = pos / (N / 4), c4 = pos % (N / 4);
-        const int idx = gg < live ? gg * (2 * N / 4) + c4 : c4;           // (32-bit lane offsets; rows that do not exist re-read pair 0)
-        va[q] = ld_stream(&src[idx]);                                     // (frames are read once)
-        vb[q] = ld_stream(&src[idx + N / 4]);
+        for (int q = 0; q < NPOS; ++q) {
+            const int pos = tid + q * NT;
+            const int gg = pos / (N / 4), c4 = pos % (N / 4);
+            const int idx = gg < live ? gg * (2 * N / 4) + c4 : c4;
+            wa[q] = __builtin_nontemporal_load(&src[idx]);
+            wb[q] = __builtin_nontemporal_load(&src[idx + N / 4]);
+        }
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            va[q] = make_float4((float)(wa[q] & 255u), (float)((wa[q] >> 8) & 255u), (float)((wa[q] >> 16) & 255u), (float)(wa[q] >> 24));
+            vb[q] = make_float4((float)(wb[q] & 255u), (float)((wb[q] >> 8) & 255u), (float)((wb[q] >> 16) & 255u), (float)(wb[q] >> 24));
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(in_v) + pair0 * 2 * N);
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            const int pos = tid + q * NT;
+            const int gg = pos / (N / 4), c4 = pos % (N / 4);
+            const int idx = gg < live ? gg * (2 * N / 4) + c4 : c4;           // (32-bit lane offsets; rows that do not exist re-read pair 0)
+            va[q] = ld_stream(&src[idx]);                                     // (frames are read once)
+            vb[q] = ld_stream(&src[idx + N / 4]);
+        }
     }
 #pragma unroll
     for (int q = 0; q < NPOS; ++q) {
@@ -689,14 +709,15 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int N> static hipError_t run_r2c_rows(const float* in, float2* mid, long npairs, int Wc, hipStream_t st)
+template <int N> static hipError_t run_r2c_rows(const void* in, float2* mid, long npairs, int Wc, hipStream_t st, bool in_u8)
 {
     using Cfg = RowCfg<N>;
     const size_t lds = sizeof(float2) * (Cfg::G * Cfg::PL);
-    hipError_t e = allow_lds(r2c_rows_kernel<N>, lds);
+    hipError_t e = in_u8 ? allow_lds(r2c_rows_kernel<N, true>, lds) : allow_lds(r2c_rows_kernel<N, false>, lds);
     if (e != hipSuccess) return e;
     const long blocks = (npairs + Cfg::G - 1) / Cfg::G;
-    r2c_rows_kernel<N><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(in, mid, npairs, Wc);
+    if (in_u8) r2c_rows_kernel<N, true><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(in, mid, npairs, Wc);
+    else r2c_rows_kernel<N, false><<<dim3((unsigned)blocks), dim3(Cfg::NT), lds, st>>>(in, mid, npairs, Wc);
     return hipGetLastError();
 }
 template <int N> static hipError_t run_c2r_rows(const float2* mid, float* out, long npairs, int Wc, float scale, hipStream_t st)
@@ -868,7 +889,7 @@ hipError_t launch_c2r_any(const float2* in, float* out, float2* w1, float2* w2, 
 }
 
 // `in` non-null: run the row pass (in -> mid); `out` non-null: run the column pass (mid -> out).
-hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st, hipEvent_t done)
+hipError_t launch_r2c(const void* in, float2* out, float2* mid, long planes, int Nx, int Ny, int Nxs, int Nys, hipStream_t st, hipEvent_t done, bool in_u8)
 {
     if (!fft_size_supported(Nx) || !fft_size_supported(Ny) || Nxs > Nx || Nys > Ny || Nys < 8 || Nxs < 2 || (Nys & (Nys - 1)) || (Nxs & 1))
         return hipErrorInvalidValue;                     // (Nys a power of two: the row pass indexes its packed columns with shifts)
@@ -877,7 +898,7 @@ hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, in
     const long npairs = planes * Nx / 2;
     hipError_t e = hipSuccess;
     if (in) {
-        AEFFT_N_SWITCH(Ny, e = run_r2c_rows<NN>(in, mid, npairs, Wc, st); break)
+        AEFFT_N_SWITCH(Ny, e = run_r2c_rows<NN>(in, mid, npairs, Wc, st, in_u8); break)
         if (e != hipSuccess) return e;
     }
     if (out) {

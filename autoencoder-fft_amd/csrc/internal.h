@@ -21,8 +21,9 @@ bool fft_size_supported(int n);
 // Batched 2-D R2C with optional fused spectral crop (== fft.cu:764 `fft` followed by
 // fft.cu:87 `resize` down-sampling to Nxs x Nys).  in [planes][Nx][Ny] real ->
 // out [planes][Nxs][Nys/2+1] complex.  `mid` is a workspace of planes*Nx*(Nys/2) complex.
-hipError_t launch_r2c(const float* in, float2* out, float2* mid, long planes, int Nx, int Ny,
-                      int Nxs, int Nys, hipStream_t st, hipEvent_t done = nullptr /* recorded by the column pass's own completion signal */);
+// in_u8: `in` holds 8-bit pixels instead of floats (the row pass converts on load).
+hipError_t launch_r2c(const void* in, float2* out, float2* mid, long planes, int Nx, int Ny,
+                      int Nxs, int Nys, hipStream_t st, hipEvent_t done = nullptr /* recorded by the column pass's own completion signal */, bool in_u8 = false);
 // Batched 2-D C2R with optional fused spectral zero-pad (== `resize` up-sampling from
 // Nxi x Nyi, then cufftExecC2R, then * scale).  in [planes][Nxi][Nyi/2+1] -> out [planes][Nx][Ny].
 // opin (nullable): the input spectra are not stored but evaluated from an operator (see inv_cols_kernel): plane (b, d) at bin t is
@@ -251,6 +252,7 @@ struct UpdateArgs {
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
 hipError_t launch_vec_add(float* out, const float* a, const float* b, long n, hipStream_t st);      // out = a + b
+hipError_t launch_u8_to_f32(float* out, const unsigned char* in, long n, hipStream_t st);             // out = (float)in
 struct UpdateGroup { UpdateArgs a[8]; int n; int start[9]; };
 hipError_t launch_update_group(UpdateGroup& g, hipStream_t st);                                       // up to 8 pairs, one launch                                      // fft.cu:605 / 657
 size_t gradient_diff_ws_floats(int dM, int dD, int Nk, int Nl);      // floats of launch_gradient_diff's workspace (chunk partial sums)

@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void vec_add_kernel(float* __restrict__ out, c
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(float* __restrict__ out, const unsigned char* __restrict__ in, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+hipError_t launch_u8_to_f32(float* out, const unsigned char* in, long n, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    u8_to_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(out, in, n);
+    return hipGetLastError();
+}
 hipError_t launch_vec_add(float* out, const float* a, const float* b, long n, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;

@@ -159,7 +159,7 @@ def cpu_baseline(N, scale, maps=(8, 16, 32, 64), D=3, Nk=5):
                                        "method": "EXTRAPOLATED, not timed: pair-1 time x iteration-count ratio of the backprop loop nest"}}
 
 
-def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2, sym=0, maxdiff=0, flags=(), del0=0.2):
+def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2, sym=0, maxdiff=0, flags=(), del0=0.2, u8=False):
     """A short timed run of one BASELINE config through the same step the headline uses, with its own HIP-event profile:
     frames/s, algorithmic bytes of the kernel groups as launched, whole-step fraction of the HBM peak, the dominant
     kernel's roofline object, and the first / last per-pair post-update MSE of the run (a non-finite value is FLAGGED, the
@@ -173,6 +173,8 @@ def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2
         dev = f"cuda:{ctx.device}"
         frames = synth_frames(torch, B, D, N, dev, first_index=0)
         recon = torch.empty_like(frames)
+        if u8:
+            frames = frames.to(torch.uint8)      # (the synthetic pixels are integers 0..255: the same values, a quarter of the bytes)
         mse = torch.zeros(len(maps), dtype=torch.float32, device=dev)
 
         def step():
@@ -490,6 +492,8 @@ def main():
         variants = {
             "per_frame_form": fft_variant(aefft, torch, np, ctx, "cfg3-P2, per-frame form (NOOPFORM: every layer for every frame, round 1's step)",
                                           512, M4, 2, 32, steps=20, warmup=5, flags=("NOOPFORM",)),
+            "u8_frames": fft_variant(aefft, torch, np, ctx, "cfg3-P2 with the frames resident as 8-bit pixels (aefft_net_step_grad_u8: what a camera delivers; the headline "
+                                     "keeps the reference's float frames); same pixel values, same results", 512, M4, 2, 32, steps=200, warmup=20, u8=True),
             "p1": fft_variant(aefft, torch, np, ctx, "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512; 5.7 GB of kernel spectra)",
                               512, M4, 1, 32, steps=10, warmup=2),
             "cfg2": fft_variant(aefft, torch, np, ctx, "cfg2: 256x256x3, 3 pairs 3->8->16->32, 5x5, pool 2/layer, B = 1 (BASELINE configs[1])",

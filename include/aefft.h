@@ -263,6 +263,12 @@ int aefft_net_train_pair(aefft_net* net, int l, int n_iter, float del0, int maxd
  * reference itself never exports (fft_l = 0) are formed on demand by aefft_net_get_layer.
  * Momentum persists across steps (reset with aefft_net_reset_momentum). */
 int aefft_net_step_grad(aefft_net* net, const float* frames_d, float* recon_d);
+/* The same calls on 8-BIT frames (frames_d [B][D][Nx][Ny] unsigned char, planar: what a camera delivers -- the reference's application turns each
+ * 8-bit pixel into a float on the host, `(float)col[c]`, netlib.cpp:37-51 ImageToSpin_C, called at autoencoder.cpp:125): the input transform
+ * converts on load, a quarter of its reads; results are those of the float call on the same pixel values, bit for bit.  Power-of-two frame
+ * sizes; 16-byte aligned.  aefft_net_get_layer(0) returns the pixels as floats. */
+int aefft_net_step_grad_u8(aefft_net* net, const unsigned char* frames_d, float* recon_d);
+int aefft_net_forward_u8(aefft_net* net, const unsigned char* frames_d, float* recon_d);
 /* Opt-in input prefetch for pipelined training loops.  enable = 1 asserts that the frames handed to
  * aefft_net_step_grad are COMPLETE in device memory when the call is made (not merely ordered on the
  * context stream, e.g. a loader that synchronises its own copy stream): their R2C then runs on an

@@ -293,3 +293,47 @@ def test_layer_exports_after_step_apply_are_one_consistent_forward(ctx, flags):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
     net.close(); fresh.close(); net2.close()
+
+
+@pytest.mark.parametrize("path", ["", "NOOPFORM"])
+def test_8bit_frames_give_the_float_results_bit_for_bit(ctx, flags, path):
+    """aefft_net_step_grad_u8 / aefft_net_forward_u8 (include/aefft.h): frames resident as 8-bit pixels, converted by the input transform's row pass
+    (the reference's application converts each camera pixel with `(float)col[c]` on the host, netlib.cpp:37-51).  The conversion is exact, so every
+    result is that of the float call on the same pixel values BIT FOR BIT: reconstruction, packed gradients, the weights after three steps, the
+    layer-0 export.  Operator form and per-frame form."""
+    import torch
+    flags(*path.split(","))
+    rng = np.random.default_rng(808)
+    D, N, maps, Nk, s, B = 3, 64, [4, 6, 5], 5, 2, 3
+    L = len(maps)
+    ws, dD = [], D
+    for dM in maps:
+        q32 = lambda a: a.astype(np.float32)
+        ws.append((q32(rng.uniform(-1, 1, (dM, dD, Nk, Nk))), q32(rng.uniform(-1, 1, dM)), q32(rng.uniform(-1, 1, (dD, dM, Nk, Nk))), q32(rng.uniform(-1, 1, dD)))); dD = dM
+    px = [np.floor(rng.uniform(0, 256, (B, D, N, N))) for _ in range(3)]
+    xf = [ctx.dev(p) for p in px]
+    xb = [t.to(torch.uint8) for t in xf]
+    assert xb[0].dtype == torch.uint8 and xb[0].element_size() == 1
+    nets = []
+    for _ in range(2):
+        net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
+        for l, w in enumerate(ws):
+            net.set_pair(l, *w)
+        nets.append(net)
+    nf, nb = nets
+    rf, rb = ctx.empty(B, D, N, N), ctx.empty(B, D, N, N)
+    nf.forward(xf[0], rf); nb.forward(xb[0], rb)
+    assert np.array_equal(host(rf), host(rb))
+    for i in range(3):
+        nf.step_grad(xf[i], rf); nb.step_grad(xb[i], rb)
+        assert np.array_equal(host(rf), host(rb)), i
+        assert np.array_equal(host(nf.grad_buffer()), host(nb.grad_buffer())), i
+        nf.step_apply(0.2); nb.step_apply(0.2)
+    for l in range(L):
+        for u, v in zip(nf.get_pair(l), nb.get_pair(l)):
+            assert np.array_equal(u, v)
+    lf, lb = nf.get_layers(), nb.get_layers()
+    assert np.array_equal(host(lb[0]), px[2].astype(np.float32))            # layer 0: the pixels as floats
+    for a, b in zip(lf, lb):
+        assert np.array_equal(host(a), host(b))
+    nf.close(); nb.close()
