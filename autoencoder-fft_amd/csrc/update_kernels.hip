@@ -133,6 +133,20 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t st)
 // fill the chip; the chunks' partial sums lie side by side and gdiff_finish_kernel adds them in chunk order (deterministic: the
 // replicas of a data-parallel run must stay bit-identical).  No (dM dD)^2 distance matrix is stored (537 MB at cfg5's 64->128 pair).
 // ------------------------------------------------------------------------------------------
+#ifndef AEFFT_X_GDEXP
+#define AEFFT_X_GDEXP 1
+#endif
+#ifndef AEFFT_X_GDKPT
+#define AEFFT_X_GDKPT 1
+#endif
+#ifndef AEFFT_X_GDUNR
+#define AEFFT_X_GDUNR 2
+#endif
+#define GD_UNROLL AEFFT_X_GDUNR
+// kernels per thread of the partner loop (workgroup = 256 * kpt rows).  Two, sharing each partner row's LDS reads (148 registers at 5x5, 3 waves per SIMD),
+// measured 254 (276-285 with two partners per trip) against 244 us for one kernel per thread and two partners per trip at cfg5: one.
+constexpr int gd_kpt(int kl) { return kl <= 25 ? AEFFT_X_GDKPT : 1; }
+constexpr int gd_rows(int kl) { return 256 * gd_kpt(kl); }
 template <int KL>
 __device__ __forceinline__ void gdiff_part_body(const float* __restrict__ c, const float* __restrict__ f, float* __restrict__ part,
                                                 int dM, int dD, int chunk, int bx, int by, int bz, int nchunks)
@@ -143,6 +157,7 @@ __device__ __forceinline__ void gdiff_part_body(const float* __restrict__ c, con
     const int np = dM * dD;
     const bool isf = bz != 0;                              // rows of f are (d,m)-ordered, rows of c (m,d)-ordered
     const float* __restrict__ w = isf ? f : c;
+    static_assert(AEFFT_X_GDEXP || gd_kpt(KL) == 1, "the difference forms own one kernel per thread");
     const int i = bx * 256 + threadIdx.x;
     const int j0 = by * chunk, j1 = min(np, j0 + chunk);
     // partner taps -> LDS (coalesced), zero padding of the pitch
@@ -152,6 +167,83 @@ __device__ __forceinline__ void gdiff_part_body(const float* __restrict__ c, con
     }
 #ifndef AEFFT_X_GDPK
 #define AEFFT_X_GDPK 1
+#endif
+#if AEFFT_X_GDEXP
+    // |a - b|^2 = |a|^2 + |b|^2 - 2 a.b and  sum_j w_j (a - b_j) = a sum_j w_j - sum_j w_j b_j:  per partner KP/2 packed FMAs for the dot product, one
+    // FMA, ONE reciprocal, KP/2 packed FMAs for the weighted partner sum -- two thirds of the instructions of the difference form below.  The partner
+    // norms are formed once per chunk and kept in the last padding slot of each LDS row (this thread's padding taps are zero, so the slot drops out
+    // of the dot product; the padding lanes of the sums are not stored).  A thread owns GD_KPT kernels (rows i, i + 256, ...: gd_kpt).  Rounding: the squared distance is exact
+    // to a few ulp of |a|^2 + |b|^2 instead of of itself; identical kernels still give 1/0 and NaN sums like the reference's 0/0 (the norm and the dot
+    // product are the same FMA chain).
+    {
+        static_assert(KP > KL, "a padding slot for the norm");
+        constexpr int KH = KP / 2, GD_KPT = gd_kpt(KL);
+        const int nj = j1 - j0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nj; t += 256) {
+            const float4* row = reinterpret_cast<const float4*>(sh + t * KP);
+            float2 n2 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < KP / 4; ++q) { const float4 v = row[q]; n2 = n2 + make_float2(v.x, v.y) * make_float2(v.x, v.y); n2 = n2 + make_float2(v.z, v.w) * make_float2(v.z, v.w); }
+            sh[t * KP + KP - 1] = n2.x + n2.y;
+        }
+        float2 ca2[GD_KPT][KH], acc2[GD_KPT][KH];
+        float ni[GD_KPT], sw[GD_KPT];
+        int i_f[GD_KPT], i_s[GD_KPT];
+        const int fast_n = isf ? dM : dD;                                          // the index that runs fastest along a tensor's rows
+#pragma unroll
+        for (int u = 0; u < GD_KPT; ++u) {
+            const int ii = min(bx * (256 * GD_KPT) + u * 256 + (int)threadIdx.x, np - 1);
+            float2 ni2 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+                ca2[u][h] = make_float2(2 * h < KL ? w[(long)ii * KL + 2 * h] : 0.f, 2 * h + 1 < KL ? w[(long)ii * KL + 2 * h + 1] : 0.f);
+                acc2[u][h] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int h = 0; h < KH; ++h) ni2 = ni2 + ca2[u][h] * ca2[u][h];
+            ni[u] = ni2.x + ni2.y; sw[u] = 0.f;
+            i_f[u] = ii % fast_n; i_s[u] = ii / fast_n;
+        }
+        __syncthreads();
+        // the partner's (m, d) as running counters (uniform: a division per partner was ~50 scalar instructions of a ~90-instruction iteration); the
+        // pair test as a select, not a branch around the LDS reads
+        int jf = j0 % fast_n, js = j0 / fast_n;
+#pragma unroll GD_UNROLL
+        for (int j = j0; j < j1; ++j) {
+            const float4* row = reinterpret_cast<const float4*>(sh + (j - j0) * KP);
+            float2 b2[KH];
+#pragma unroll
+            for (int q = 0; q < KP / 4; ++q) { const float4 v = row[q]; b2[2 * q] = make_float2(v.x, v.y); b2[2 * q + 1] = make_float2(v.z, v.w); }
+            const float nb = b2[KH - 1].y;                                         // |b|^2 (the row's last slot; ca2's is zero)
+#pragma unroll
+            for (int u = 0; u < GD_KPT; ++u) {
+                float2 dot2 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int h = 0; h < KH; ++h) dot2 = dot2 + ca2[u][h] * b2[h];
+                const float den = fmaf(-2.f, dot2.x + dot2.y, ni[u] + nb);
+                // pairs need m1 != m AND d1 != d (:724)
+                const float wgt = (jf != i_f[u] && js != i_s[u]) ? __builtin_amdgcn_rcpf(den) : 0.f;
+                const float2 w2 = make_float2(wgt, wgt);
+                sw[u] += wgt;
+#pragma unroll
+                for (int h = 0; h < KH; ++h) acc2[u][h] = acc2[u][h] + b2[h] * w2;
+            }
+            if (++jf == fast_n) { jf = 0; ++js; }
+        }
+#pragma unroll
+        for (int u = 0; u < GD_KPT; ++u) {
+            const int i = bx * (256 * GD_KPT) + u * 256 + (int)threadIdx.x;
+            if (i >= np) continue;
+            float* dst = part + (((long)bz * nchunks + by) * np + i) * KL;
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+                if (2 * h < KL) dst[2 * h] = fmaf(ca2[u][h].x, sw[u], -acc2[u][h].x);
+                if (2 * h + 1 < KL) dst[2 * h + 1] = fmaf(ca2[u][h].y, sw[u], -acc2[u][h].y);
+            }
+        }
+        return;
+    }
 #endif
 #if AEFFT_X_GDPK
     // taps in PAIRS (native 2-vectors: the back end selects v_pk_add_f32 / v_pk_fma_f32, two taps per lane and issue slot): per partner
@@ -244,7 +336,7 @@ __global__ __launch_bounds__(256) void gdiff_part_group_kernel(const GdiffGroup 
     for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
     const GdiffProb& q = g.q[p];
     int blk = blockIdx.x - g.start[p];
-    const int rt = (q.dM * q.dD + 255) / 256;
+    const int rt = (q.dM * q.dD + gd_rows(KL) - 1) / gd_rows(KL);
     const int bx = blk % rt; blk /= rt;
     const int by = blk % q.nchunks, bz = blk / q.nchunks;
     gdiff_part_body<KL>(q.c, q.f, q.part, q.dM, q.dD, q.chunk, bx, by, bz, q.nchunks);
@@ -386,7 +478,7 @@ hipError_t launch_gradient_diff(const float* c, const float* f, const float* b, 
     }
     int chunk, nchunks;
     gdiff_geom(np, kl, &chunk, &nchunks);
-    const dim3 grid((unsigned)((np + 255) / 256), (unsigned)nchunks, 2);
+    const dim3 grid((unsigned)((np + gd_rows(kl) - 1) / gd_rows(kl)), (unsigned)nchunks, 2);
     const size_t lds = sizeof(float) * (size_t)chunk * ((kl + 3) & ~3);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (kl == 9) gdiff_part_kernel<9><<<grid, 256, lds, st>>>(c, f, part_ws, dM, dD, chunk);
@@ -410,7 +502,7 @@ hipError_t launch_gradient_diff_group(GdiffGroup& g, int Nk, int Nl, hipStream_t
         GdiffProb& q = g.q[i];
         const long np = (long)q.dM * q.dD;
         gdiff_geom(np, kl, &q.chunk, &q.nchunks);
-        g.start[i] = (int)total; total += ((np + 255) / 256) * q.nchunks * 2;
+        g.start[i] = (int)total; total += ((np + gd_rows(kl) - 1) / gd_rows(kl)) * q.nchunks * 2;
         g.fstart[i] = (int)ftotal; ftotal += (2 * np * kl + q.dM + q.dD + 255) / 256;
         lds = std::max(lds, sizeof(float) * (size_t)q.chunk * ((kl + 3) & ~3));
     }
