@@ -211,11 +211,12 @@ def fft_variant(aefft, torch, np, ctx, label, N, maps, scale, B, steps, warmup=2
             "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_bytes_per_launch": dom["bytes"] / dom["launches"],
             "share_of_kernel_time": dom["ms"] / sum(v["ms"] for v in prof.values()), "traffic": None}
     if name == "gradient_diff":
-        # the multiobjective term is arithmetic, not traffic: per kernel pair Nk*Nl subtractions, 2 Nk*Nl FMAs and a reciprocal
-        # (fft_backproplib.cu:709-753 re-associated, update_kernels.hip) against the fp32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+        # the multiobjective term is arithmetic, not traffic: per kernel pair 2 Nk*Nl FMAs (the dot product of the expanded squared distance and the
+        # weighted partner sum), a reciprocal and three more operations (fft_backproplib.cu:709-753 re-associated, update_kernels.hip) against the fp32
+        # vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s); c and f each
         dD, flops = 3, 0.0
         for dM in maps:
-            flops += 2.0 * (dM * dD) ** 2 * (5.0 * Nk * Nk + 1.0); dD = dM
+            flops += 2.0 * (dM * dD) ** 2 * (4.0 * Nk * Nk + 4.0); dD = dM
         t_s = dom["ms"] / 2 * 1e-3
         roof = {"bound": "valu", "kernel": KERNEL_NAMES.get(name, name), "achieved": flops / t_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                 "frac": flops / t_s / 1e12 / 157.3, "avg_us": avg_s * 1e6, "launches_per_step": dom["launches"] / 2, "algo_flops_per_step": flops,
