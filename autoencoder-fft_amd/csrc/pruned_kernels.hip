@@ -90,7 +90,7 @@ __device__ __forceinline__ void kspec_rows(const float* __restrict__ c, float2* 
 // transforms the planes (d', d0 .. d0+np) forms their taps itself, from the pair's taps READ THROUGH the pending update (TapUpd):
 // f'[d'][.] and c'[.][d0..] staged in LDS, thread <-> (plane, output row tx, slice of m) owns the T outputs of that row (per (m, k)
 // one row of f' and one of c' feed NK*NK FMAs in registers), slices summed in slice order.  taps_s [np][T*T].
-template <int NK>
+template <int NK, int MU = 2>
 __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd, int dp, int d0, int np, float* __restrict__ taps_s, float* __restrict__ work)
 {
     constexpr int T = 2 * NK - 1, KK = NK * NK;
@@ -152,11 +152,10 @@ __device__ __forceinline__ void gtaps_stage(const GtapSrc& gs, const TapUpd& upd
     for (int y = 0; y < T; ++y) acc[y] = 0.f;
     if (work_thr) {
         const int i = it / T, tx = it - i * T;
-        // (the m loop rolled: unrolled by 2 its LDS reads are hoisted into 153 registers for the spectra launch -- 3 workgroups per CU; rolled 128 -- 4)
-#ifndef AEFFT_X_GT_MU
-#define AEFFT_X_GT_MU 1
-#endif
-#pragma unroll AEFFT_X_GT_MU
+        // (MU: the m loop's unroll factor.  Unrolled by 2 its LDS reads are hoisted into 153 registers for the spectra launch -- 3 workgroups per CU;
+        // rolled 128 -- 4, which the launches with G' problems want (cfg3-P2 19.1 -> 18.5 us) and the planar-spectra launch of cfg3-P1 does NOT
+        // (5.7 GB of plane writes: 1 375 us at 153 registers, 1 460-1 750 at 128): the launcher picks the instantiation, run_kspec_group)
+#pragma unroll MU
         for (int m = sl; m < dM; m += nsl) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -239,7 +238,7 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
 }
 
 // the G' form of kspec_body: workgroup = (d', tile of ppb d's) x row chunk; the taps come from gtaps_stage
-template <int NK>
+template <int NK, int MU>
 __device__ __forceinline__ void gspec_gbody(const GtapSrc& gs, float2* __restrict__ G, const float2* __restrict__ tw, int Nx, int Ny,
                                             int rows_per_chunk, int ppb, int bx, int by, float2* lds, const TapUpd& upd)
 {
@@ -257,7 +256,7 @@ __device__ __forceinline__ void gspec_gbody(const GtapSrc& gs, float2* __restric
     const int tiles = (gs.dD + ppb - 1) / ppb;
     const int dp = bx / tiles, d0 = (bx - dp * tiles) * ppb;
     const int np = min(ppb, gs.dD - d0);
-    gtaps_stage<NK>(gs, upd, dp, d0, np, taps_s, work);
+    gtaps_stage<NK, MU>(gs, upd, dp, d0, np, taps_s, work);
     __syncthreads();
     AEFFT_WGSTAMP(3, 3);
     if (pl >= np) return;
@@ -275,10 +274,10 @@ __global__ __launch_bounds__(320) void kspec_kernel(const float* __restrict__ ke
 }
 
 // all pairs' kernel spectra in one launch: problem p owns workgroups [start[p], start[p+1]), plane groups fastest
-template <int NK, int NL>
 #ifndef AEFFT_X_KSPEC_W
 #define AEFFT_X_KSPEC_W 1
 #endif
+template <int NK, int NL, int MU>
 __global__ __launch_bounds__(320, AEFFT_X_KSPEC_W) void kspec_group_kernel(const PrunedGroup g, const float2* __restrict__ tw, const PackArgs pk, const BiasUpdGroup bu, const int nbias_start)
 {
     AEFFT_WGTIME(3);
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(320, AEFFT_X_KSPEC_W) void kspec_group_kernel(const
     const PrunedProb& q = g.q[p];
     if constexpr (NK == NL && (NK == 3 || NK == 5)) {
         if (g.gsrc[p].f) {                                // (uniform) a G' problem: the (2NK-1)^2 taps are formed in the workgroup
-            gspec_gbody<NK>(g.gsrc[p], static_cast<float2*>(q.dst), tw, q.Nx, q.Ny, g.rows[p], g.ppb[p], lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p]);
+            gspec_gbody<NK, MU>(g.gsrc[p], static_cast<float2*>(q.dst), tw, q.Nx, q.Ny, g.rows[p], g.ppb[p], lin % g.pblocks[p], lin / g.pblocks[p], lds, g.upd[p]);
             return;
         }
     }
@@ -775,8 +774,11 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
         g.start[p] = total; total += g.pblocks[p] * chunks;
     }
     g.start[g.n] = total;
+    bool has_g = false;                                   // (which instantiation: see gtaps_stage)
+    for (int p = 0; p < g.n; ++p) has_g = has_g || g.gsrc[p].f != nullptr;
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_group_kernel<NK, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = has_g ? hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_group_kernel<NK, NL, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                   : hipFuncSetAttribute(reinterpret_cast<const void*>(kspec_group_kernel<NK, NL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     int threads = 256;                                    // one thread per (plane in group, column)
@@ -784,7 +786,8 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
     if (threads > 320) return hipErrorInvalidValue;
     if (extra) lds = std::max(lds, kspec_packed_lds(NK));
     const int nb = bu ? bu->n : 0;
-    kspec_group_kernel<NK, NL><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
+    if (has_g) kspec_group_kernel<NK, NL, 1><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
+    else kspec_group_kernel<NK, NL, 2><<<dim3(total + extra + nb), threads, lds, st>>>(g, tw, extra ? *pk : g_pack_none, nb ? *bu : g_bu_none, total + extra);
     return hipGetLastError();
 }
 
