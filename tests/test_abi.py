@@ -100,3 +100,36 @@ def test_unknown_name_in_AEFFT_FLAGS_fails_context_creation(built):
             "h = C.c_void_p(); print(L.aefft_ctx_create(C.byref(h), 0, None, 1))" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AEFFT_FLAGS="NOMFMA,BOGUS"))
     assert out.stdout.strip().endswith("1") and "BOGUS" in out.stderr, (out.stdout, out.stderr)
+
+
+def test_hot_kernels_do_not_spill():
+    """The back end's per-kernel resource tables (build/*.rsrc, written by the Makefile with -Rpass-analysis=kernel-resource-usage): no kernel of the
+    training step may use scratch memory (a spilled register is a memory round trip inside loops that are bound by exactly those; a second call site of
+    an inlined body once turned the tail launch's 23 us into 195), and the launches whose residency the design counts on keep their register budgets
+    (tail_kernel<true> <= 80, kspec_group_kernel<5,5,1> <= 128)."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "autoencoder-fft_amd", "csrc", "build", "*.rsrc"))
+    if not files:
+        pytest.skip("no resource tables (library built before the Makefile wrote them)")
+    rows = {}
+    for f in files:
+        name = None
+        for line in open(f):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1); rows[name] = {}
+            for key, pat in (("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vgprs", r" VGPRs: (\d+)")):
+                m = re.search(pat, line)
+                if m and name:
+                    rows[name][key] = int(m.group(1))
+    assert len(rows) > 50
+    legacy = ("contract_kernelILi",)          # the scalar-FMA contraction (AEFFT_F_NOMFMA / odd shapes): 20 bytes, not on the step's path
+    spills = {k: v["scratch"] for k, v in rows.items() if v.get("scratch", 0) > 0 and not any(t in k for t in legacy)}
+    assert not spills, spills
+    budget = {"tail_kernelILb1E": 80, "kspec_group_kernelILi5ELi5ELi1E": 128, "msgrad_kernel": 128, "wgrad_taps_kernelILi5E": 128}
+    for frag, cap in budget.items():
+        hit = [k for k in rows if frag in k]
+        assert hit, frag
+        for k in hit:
+            assert rows[k]["vgprs"] <= cap, (k, rows[k])
