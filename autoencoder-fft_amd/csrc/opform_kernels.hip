@@ -91,6 +91,9 @@ hipError_t launch_basis_fill(float2* A0, int D0, long P0, hipStream_t st)
 #ifndef AEFFT_X_MSGRAD_W
 #define AEFFT_X_MSGRAD_W 1
 #endif
+// FC: frames per batch of loads.  8 -- every frame of a pair-0 thread at cfg3 in ONE round trip, 118 registers, 4 workgroups per CU: the launch is one
+// round of 976 workgroups there.  4 -- 96 registers, 5 per CU: for launches of several rounds (cfg5: 3 940 workgroups), which are bound by their slots.
+template <int FC>
 __global__ __launch_bounds__(256, AEFFT_X_MSGRAD_W) void msgrad_kernel(const SgradGroup g)
 {
     AEFFT_WGTIME(0);
@@ -136,7 +139,6 @@ __global__ __launch_bounds__(256, AEFFT_X_MSGRAD_W) void msgrad_kernel(const Sgr
     for (int d = 0; d < 3; ++d) sx[d] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int e = 0; e < 6; ++e) mm[e] = make_float2(0.f, 0.f);
-    constexpr int FC = 8;                                           // frames per batch of loads
     for (int b0 = ry; b0 < B; b0 += RT * FC) {
         float2 x[FC][3];
 #pragma unroll
@@ -280,11 +282,14 @@ hipError_t launch_msgrad_group(SgradGroup& g, hipStream_t st)
     }
     if (total >= (1L << 31) || lds > 150 * 1024) return hipErrorInvalidValue;
     g.start[g.n] = (int)total;
+    const bool rounds = total > 1024;                                // (more workgroups than 4 per CU hold at once)
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = rounds ? hipFuncSetAttribute(reinterpret_cast<const void*>(msgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(msgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    msgrad_kernel<<<dim3((unsigned)total), 256, lds, st>>>(g);
+    if (rounds) msgrad_kernel<4><<<dim3((unsigned)total), 256, lds, st>>>(g);
+    else msgrad_kernel<8><<<dim3((unsigned)total), 256, lds, st>>>(g);
     return hipGetLastError();
 }
 
