@@ -1602,7 +1602,10 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // through that dispatch's own completion signal
     // (reconstructions beyond ~256 MB -- 32 frames of 1024^2 -- stay on the context stream: beside their row pass the pruned inverse transform
     // of S stretches from 42 to 145 us and the side stream costs more than it hides, 1.084 vs 1.057 ms per cfg5 step; at cfg3 it saves 15 of 203 us)
-    const bool overlap_pays = (double)n->B * n->D * n->Nx * n->Ny * 4.0 <= 256e6;
+    // ... and reconstructions below ~8 MB (cfg2: one 256^2 frame, 11 us of kernels) stay there as well: the fork and join packets cost more than the
+    // two kernels they would hide (0.074 vs 0.076 ms per cfg2 step)
+    const double recon_bytes = (double)n->B * n->D * n->Nx * n->Ny * 4.0;
+    const bool overlap_pays = recon_bytes <= 256e6 && recon_bytes >= 8e6;
     const bool want_fork = chain_plan && recon_d && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && overlap_pays && !ctx->prof &&
                            !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
     const bool need_chain = chain_plan && !n->chain_valid;
