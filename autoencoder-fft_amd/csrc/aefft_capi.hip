@@ -112,7 +112,8 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOGROUP", AEFFT_F_NOGROUP}, {"NOMFMA", AEFFT_F_NOMFMA}, {"NOGFWD", AEFFT_F_NOGFWD}, {"NOOVERLAP", AEFFT_F_NOOVERLAP},
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
-    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}, {"NOLAZYMSE", AEFFT_F_NOLAZYMSE}};
+    {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}, {"NOLAZYMSE", AEFFT_F_NOLAZYMSE},
+    {"SMALLOVERLAP", AEFFT_F_SMALLOVERLAP}};
 // The switches named by AEFFT_FLAGS stay on for the life of the process: aefft_ctx_set_flags ORs its argument onto them (a test fixture
 // that restores "no flags" does not clear an AEFFT_FLAGS=POISON run).  A name the library does not know is an error, not a silent
 // default run: the first aefft_ctx_create fails with AEFFT_EINVAL and says which.
@@ -1605,7 +1606,7 @@ static int net_forward(aefft_net* n, const float* frames_d, float* recon_d, bool
     // ... and reconstructions below ~8 MB (cfg2: one 256^2 frame, 11 us of kernels) stay there as well: the fork and join packets cost more than the
     // two kernels they would hide (0.074 vs 0.076 ms per cfg2 step)
     const double recon_bytes = (double)n->B * n->D * n->Nx * n->Ny * 4.0;
-    const bool overlap_pays = recon_bytes <= 256e6 && recon_bytes >= 8e6;
+    const bool overlap_pays = recon_bytes <= 256e6 && (recon_bytes >= 8e6 || flag(AEFFT_F_SMALLOVERLAP));
     const bool want_fork = chain_plan && recon_d && ctx->aux[0] != nullptr && !flag(AEFFT_F_NOOVERLAP) && overlap_pays && !ctx->prof &&
                            !(n->input_ready && !flag(AEFFT_F_NODEFER)) && ctx->cur == ctx->stream;
     const bool need_chain = chain_plan && !n->chain_valid;

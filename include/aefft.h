@@ -70,7 +70,8 @@ enum {
     AEFFT_F_NOGROUP = 1 << 4,     /* one launch per pair instead of grouped launches */
     AEFFT_F_NOMFMA = 1 << 5,      /* scalar-FMA contraction kernels instead of the matrix-core kernel */
     AEFFT_F_NOGFWD = 1 << 6,      /* innermost pair by conv, conv instead of the collapsed operator left by the previous step */
-    AEFFT_F_NOOVERLAP = 1 << 7,   /* reconstruction inverse FFT on the context stream instead of a side stream */
+    AEFFT_F_NOOVERLAP = 1 << 7,   /* reconstruction inverse FFT on the context stream instead of a side stream (reconstructions below 8 MB or above 256 MB
+                                   * stay there anyway) */
     AEFFT_F_NOFUSECROP = 1 << 8,  /* separate resize launches instead of the crop fused into the encoder contraction */
     AEFFT_F_GTAPS = 1 << 9,       /* force G = spectrum of f (*) c (chosen by itself for HBM-sized spectra) */
     AEFFT_F_NOPREFETCH = 1 << 10, /* pipelined mode: input R2C on the context stream */
@@ -84,7 +85,8 @@ enum {
     AEFFT_F_NOFUSEUPD = 1 << 18,  /* operator form: the clipped-momentum update as its own launch instead of riding with the spectra / MSE launches */
     AEFFT_F_NOAHEAD = 1 << 19,    /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
     AEFFT_F_NORCORR = 1 << 20,    /* spatial mode: dC through the back-convolved error (a dM-plane tensor) instead of the error-input correlation R */
-    AEFFT_F_NOLAZYMSE = 1 << 21   /* aefft_net_step_apply(mse_d = NULL) still sums the MSE slots in a launch of its own instead of leaving them to the next step's gradient launch */
+    AEFFT_F_NOLAZYMSE = 1 << 21,   /* aefft_net_step_apply(mse_d = NULL) still sums the MSE slots in a launch of its own instead of leaving them to the next step's gradient launch */
+    AEFFT_F_SMALLOVERLAP = 1 << 22 /* reconstructions below 8 MB take the side stream as well (the test suite's small nets then run the two-stream path of the large ones) */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);
