@@ -1204,7 +1204,7 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
             off += (unsigned)((R * K + 1) & ~1);
         }
         g.st_n = fits ? n : 0;                                          // (0: the item runs stage by stage, chain_stage_rec)
-        if ((double)4 * CH_VMAX * (double)g.Pc >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit element offsets of the output stores)
+        if ((double)OPC * CH_VMAX * (double)g.Pc * sizeof(float2) >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit byte offsets of the output stores, st8)
     }
     long total = g.Pc;
     for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
