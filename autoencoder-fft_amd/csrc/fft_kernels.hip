@@ -472,7 +472,13 @@ __global__ __launch_bounds__(CW* N / 8) void fwd_cols_kernel(const float2* __res
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int it = tid + k * NT;
-        val[k] = ld_stream(reinterpret_cast<const float4*>(src + ((it / (CW / 2)) * Wc + 2 * (it % (CW / 2)))));     // (mid dies here; 32-bit lane offset)
+        const float4* ptr = reinterpret_cast<const float4*>(src + ((it / (CW / 2)) * Wc + 2 * (it % (CW / 2))));     // (32-bit lane offset)
+        // mid dies here: a streaming load -- when the tile's row segment is a whole 128-byte line.  Narrower tiles (1024-point columns: 8 columns,
+        // 64 bytes) share every line with the neighbouring tile of the plane, which the launch order puts on the same XCD a dozen workgroups later:
+        // a cached load lets it hit the L2 (PMC at cfg5: 362 MB fetched for 201 MB read with streaming loads; 88-94 -> 76-77 us.  Pairing the two
+        // tiles as direct neighbours on their XCD on top of that: 76-84 us, nothing)
+        if constexpr (CW * sizeof(float2) >= 128) val[k] = ld_stream(ptr);
+        else val[k] = *ptr;
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
