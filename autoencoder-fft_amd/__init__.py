@@ -23,7 +23,7 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, 1, 2, 3, 4
 # include/aefft.h AEFFT_F_* (development switches; tests/test_abi.py checks this table against the header)
 FLAGS = {n: 1 << i for i, n in enumerate(
     ["NOLAZY", "NOCOMPACT", "NOQPATH", "NOFUSEMSE", "NOGROUP", "NOMFMA", "NOGFWD", "NOOVERLAP", "NOFUSECROP", "GTAPS",
-     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD", "NORCORR", "NOLAZYMSE", "SMALLOVERLAP"])}
+     "NOPREFETCH", "NODEFER", "NOTILEDSPATIAL", "NOFAST", "NOSPLITK", "POISON", "NOOPFORM", "NOCHAIN", "NOFUSEUPD", "NOAHEAD", "NORCORR", "NOLAZYMSE", "SMALLOVERLAP", "CHAINMSE"])}
 
 
 class AefftError(RuntimeError):

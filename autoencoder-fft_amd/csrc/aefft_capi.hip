@@ -113,7 +113,7 @@ static const struct { const char* name; unsigned bit; } flag_names[] = {
     {"NOFUSECROP", AEFFT_F_NOFUSECROP}, {"GTAPS", AEFFT_F_GTAPS}, {"NOPREFETCH", AEFFT_F_NOPREFETCH}, {"NODEFER", AEFFT_F_NODEFER},
     {"NOTILEDSPATIAL", AEFFT_F_NOTILEDSPATIAL}, {"NOFAST", AEFFT_F_NOFAST}, {"NOSPLITK", AEFFT_F_NOSPLITK}, {"POISON", AEFFT_F_POISON},
     {"NOOPFORM", AEFFT_F_NOOPFORM}, {"NOCHAIN", AEFFT_F_NOCHAIN}, {"NOFUSEUPD", AEFFT_F_NOFUSEUPD}, {"NOAHEAD", AEFFT_F_NOAHEAD}, {"NORCORR", AEFFT_F_NORCORR}, {"NOLAZYMSE", AEFFT_F_NOLAZYMSE},
-    {"SMALLOVERLAP", AEFFT_F_SMALLOVERLAP}};
+    {"SMALLOVERLAP", AEFFT_F_SMALLOVERLAP}, {"CHAINMSE", AEFFT_F_CHAINMSE}};
 // The switches named by AEFFT_FLAGS stay on for the life of the process: aefft_ctx_set_flags ORs its argument onto them (a test fixture
 // that restores "no flags" does not clear an AEFFT_FLAGS=POISON run).  A name the library does not know is an error, not a silent
 // default run: the first aefft_ctx_create fails with AEFFT_EINVAL and says which.

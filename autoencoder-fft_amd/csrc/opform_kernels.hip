@@ -789,29 +789,46 @@ __device__ __forceinline__ void chain_step_load(const SRC& g, const float2* __re
     for (int u = 0; u < CH_NE; ++u) w[u] = ld8(rec, min(e0 + ((unsigned)u << ksh), elast));
     bv = g.bias(d >> 29, (d >> 28) & 1u)[r];
 }
-template <class SRC>
-__device__ __forceinline__ void chain_step_compute(const SRC& g, const int i, const float2 (&w)[CH_NE], const float bv, float2 (&acc)[OPC], float2* const Wl, const int t)
+// DUAL (the chain items of a tail launch that also owes the innermost pair's post-update MSE): the two innermost stages -- C'_{L-1} and F'_{L-1} of the
+// UPDATED weights, marked by bit 30 of their steps' offset word -- are applied to a SECOND set of OPC columns as well, the operator A_{L-1} of the step
+// that is ending (regions 2, 3, 4 of Wl: A, C' A / dM + b^, F'(.) / dD + p^).  The matrices are loaded once for both; the workgroups that used to read
+// them again for the MSE (one per bin, a quarter of the launch's instructions) are gone.
+template <bool DUAL, class SRC>
+__device__ __forceinline__ void chain_step_compute(const SRC& g, const int i, const float2 (&w)[CH_NE], const float bv, float2 (&acc)[OPC], float2 (&acc2)[OPC],
+                                                   float2* const Wl, const int t)
 {
     static_assert(OPC == 4, "two 16-byte LDS accesses per row of V");
     const unsigned d = g.desc(i), par = g.off(i) >> 31;
+    const bool dual = DUAL && ((g.off(i) >> 30) & 1u);            // (uniform)
     const unsigned R = d & 255u, K = (d >> 8) & 255u, k0 = (d >> 16) & 127u, ksh = (d >> 23) & 7u;
     const unsigned tid = threadIdx.x;
     const unsigned rr = tid >> ksh, ks = tid & ((1u << ksh) - 1u);
     const bool valid = rr < R;
+    const bool enc = (d >> 28) & 1u;
     if ((d >> 27) & 1u) {
 #pragma unroll
-        for (int c = 0; c < OPC; ++c) acc[c] = make_float2(0.f, 0.f);
+        for (int c = 0; c < OPC; ++c) { acc[c] = make_float2(0.f, 0.f); if (DUAL) acc2[c] = make_float2(0.f, 0.f); }
     }
     const float2* Vin = Wl + par * (CH_VMAX * OPC);
+    const float2* Vin2 = Wl + (enc ? 2 : 3) * (CH_VMAX * OPC);
 #pragma unroll
     for (int u = 0; u < CH_NE; ++u) {
         const unsigned k = k0 + ks + ((unsigned)u << ksh);
         const bool ok = valid && k < K;
         const float2 wv = ok ? w[u] : make_float2(0.f, 0.f);
-        const float4* vp = reinterpret_cast<const float4*>(Vin + min(k, K - 1u) * OPC);
-        const float4 va = vp[0], vb = vp[1];
-        cfma_pk(acc[0], wv, make_float2(va.x, va.y)); cfma_pk(acc[1], wv, make_float2(va.z, va.w));
-        cfma_pk(acc[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc[3], wv, make_float2(vb.z, vb.w));
+        const unsigned kk = min(k, K - 1u) * OPC;
+        {
+            const float4* vp = reinterpret_cast<const float4*>(Vin + kk);
+            const float4 va = vp[0], vb = vp[1];
+            cfma_pk(acc[0], wv, make_float2(va.x, va.y)); cfma_pk(acc[1], wv, make_float2(va.z, va.w));
+            cfma_pk(acc[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc[3], wv, make_float2(vb.z, vb.w));
+        }
+        if (dual) {
+            const float4* vp = reinterpret_cast<const float4*>(Vin2 + kk);
+            const float4 va = vp[0], vb = vp[1];
+            cfma_pk(acc2[0], wv, make_float2(va.x, va.y)); cfma_pk(acc2[1], wv, make_float2(va.z, va.w));
+            cfma_pk(acc2[2], wv, make_float2(vb.x, vb.y)); cfma_pk(acc2[3], wv, make_float2(vb.z, vb.w));
+        }
     }
     if (!((d >> 26) & 1u)) return;                                // (uniform) more chunks of this stage follow
     // the KS <= 16 lanes of a row are adjacent and aligned inside a 16-lane DPP row: lane i += lane i + 2^j (row_shl, one v_add_f32_dpp each; lanes
@@ -820,26 +837,48 @@ __device__ __forceinline__ void chain_step_compute(const SRC& g, const int i, co
     if (ksh > 0) {
 #pragma unroll
         for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<1>(acc[c].x); acc[c].y += dpp_row_shl<1>(acc[c].y); }
+        if (dual) {
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc2[c].x += dpp_row_shl<1>(acc2[c].x); acc2[c].y += dpp_row_shl<1>(acc2[c].y); }
+        }
     }
     if (ksh > 1) {
 #pragma unroll
         for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<2>(acc[c].x); acc[c].y += dpp_row_shl<2>(acc[c].y); }
+        if (dual) {
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc2[c].x += dpp_row_shl<2>(acc2[c].x); acc2[c].y += dpp_row_shl<2>(acc2[c].y); }
+        }
     }
     if (ksh > 2) {
 #pragma unroll
         for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<4>(acc[c].x); acc[c].y += dpp_row_shl<4>(acc[c].y); }
+        if (dual) {
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc2[c].x += dpp_row_shl<4>(acc2[c].x); acc2[c].y += dpp_row_shl<4>(acc2[c].y); }
+        }
     }
     if (ksh > 3) {
 #pragma unroll
         for (int c = 0; c < OPC; ++c) { acc[c].x += dpp_row_shl<8>(acc[c].x); acc[c].y += dpp_row_shl<8>(acc[c].y); }
+        if (dual) {
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc2[c].x += dpp_row_shl<8>(acc2[c].x); acc2[c].y += dpp_row_shl<8>(acc2[c].y); }
+        }
     }
-    const bool enc = (d >> 28) & 1u;
     const unsigned lv = d >> 29;
     if (valid && ks == 0) {
         const float scale = __frcp_rn((float)R);
 #pragma unroll
         for (int c = 0; c < OPC; ++c) { acc[c].x *= scale; acc[c].y *= scale; }
         if (t == 0) acc[OPC - 1].x += bv * g.NN(lv);
+        if (dual) {
+#pragma unroll
+            for (int c = 0; c < OPC; ++c) { acc2[c].x *= scale; acc2[c].y *= scale; }
+            if (t == 0) acc2[OPC - 1].x += bv * g.NN(lv);
+            float4* v2 = reinterpret_cast<float4*>(Wl + (enc ? 3 : 4) * (CH_VMAX * OPC) + rr * OPC);
+            v2[0] = make_float4(acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y); v2[1] = make_float4(acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y);
+        }
         const float4 o0 = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), o1 = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
         float4* vo = reinterpret_cast<float4*>(Wl + (par ^ 1u) * (CH_VMAX * OPC) + rr * OPC);
         vo[0] = o0; vo[1] = o1;
@@ -854,37 +893,37 @@ __device__ __forceinline__ void chain_step_compute(const SRC& g, const int i, co
     }
     __syncthreads();                                              // (uniform branch: every thread of the workgroup is here) the stage's output is complete
 #if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(Wl + 3 * CH_VMAX * OPC + 4 + OPC * OPC)[(enc ? lv : 7 - lv) & 7] = wall_clock64();    // (in LDS: a global store here would drain the pipeline it times)
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(Wl + 5 * CH_VMAX * OPC + 4 + OPC * OPC)[(enc ? lv : 7 - lv) & 7] = wall_clock64();    // (in LDS: a global store here would drain the pipeline it times)
 #endif
 }
 // straight-line code, one copy per step, the exits nested (a template recursion): with a LOOP around the rotation hipcc's wait insertion merges
 // the loop's entry and back edge into a vmcnt(0) at the header -- a drained pipeline every CH_NB steps -- and a rolled loop would index the
 // register sets dynamically (scratch)
-template <int I, class SRC>
+template <int I, bool DUAL, class SRC>
 __device__ __forceinline__ void chain_steps(const SRC& g, const float2* __restrict__ rec, const int base, const int nb, float2 (&w)[CH_NB][CH_NE], float (&bv)[CH_NB],
-                                            float2 (&acc)[OPC], float2* const Wl, const int t)
+                                            float2 (&acc)[OPC], float2 (&acc2)[OPC], float2* const Wl, const int t)
 {
     if constexpr (I < CH_BLOCK) {
         if (I >= nb) return;                                      // (uniform)
         chain_step_load(g, rec, base + min(I + CH_DEPTH, nb - 1), w[(I + CH_DEPTH) % CH_NB], bv[(I + CH_DEPTH) % CH_NB]);
-        chain_step_compute(g, base + I, w[I % CH_NB], bv[I % CH_NB], acc, Wl, t);
-        chain_steps<I + 1, SRC>(g, rec, base, nb, w, bv, acc, Wl, t);
+        chain_step_compute<DUAL>(g, base + I, w[I % CH_NB], bv[I % CH_NB], acc, acc2, Wl, t);
+        chain_steps<I + 1, DUAL, SRC>(g, rec, base, nb, w, bv, acc, acc2, Wl, t);
     }
 }
 // every step of a list: blocks of CH_BLOCK straight-line steps (cfg3: one block); the pipeline drains and refills between blocks.  `init`: fills the
 // first running vector (buffer 0 of Wl) while the first loads are in flight; the barrier behind it is this function's.
-template <class SRC, class INIT>
+template <bool DUAL, class SRC, class INIT>
 __device__ __forceinline__ void chain_run_steps(const SRC& g, const float2* __restrict__ rec, const int n, float2* const Wl, const int t, INIT init)
 {
     float2 w[CH_NB][CH_NE];
     float bv[CH_NB];
-    float2 acc[OPC];
+    float2 acc[OPC], acc2[OPC];
     for (int base = 0; base < n; base += CH_BLOCK) {
         const int nb = min(n - base, CH_BLOCK);
 #pragma unroll
         for (int j = 0; j < CH_DEPTH; ++j) chain_step_load(g, rec, base + min(j, nb - 1), w[j], bv[j]);
         if (base == 0) { init(); __syncthreads(); }
-        chain_steps<0, SRC>(g, rec, base, nb, w, bv, acc, Wl, t);
+        chain_steps<0, DUAL, SRC>(g, rec, base, nb, w, bv, acc, acc2, Wl, t);
     }
 }
 // host: the steps of one stage (R x K matrix at record offset `off`, reading running vector `par`) appended to a step list; false: the list is full
@@ -928,7 +967,7 @@ __device__ __forceinline__ void opmse_packed(const OpMseGroup& g, int p, long t,
     if (g.pst_n > 0) {
         // (as a software pipeline over the record: the stage-by-stage form below was six dependent round trips, 11 us per workgroup at cfg3)
         const PackedMseSrc src{g, q};
-        chain_run_steps(src, rec, g.pst_n, sh, (int)t, [&]() {
+        chain_run_steps<false>(src, rec, g.pst_n, sh, (int)t, [&]() {
             float2 mv = make_float2(0.f, 0.f);
             if (threadIdx.x < OPC * OPC) mv = g.Mhat[(long)threadIdx.x * g.P0 + um];
             for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; const float2 v = q.A[((long)k * dD + a) * q.P + t]; sh[i] = v; Va[i] = v; }
@@ -990,7 +1029,7 @@ __device__ __forceinline__ void opmse_dispatch(const OpMseGroup& g, float2* sh)
 }
 
 // workgroup ranges and LDS of the MSE part; `base` = workgroups of the launch in front of it (start[] are launch-wide indices)
-static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t* lds_out)
+static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t* lds_out, bool fused = false /* the chain's items form the innermost pair's MSE: no workgroups for it here */)
 {
     if (g.n < 1 || g.n > 8) return hipErrorInvalidValue;
     long total = base;
@@ -1020,7 +1059,7 @@ static hipError_t opmse_geometry(OpMseGroup& g, int base, long* nblocks, size_t*
         g.bt[i] = bt;
         lds = std::max(lds, need);
         g.start[i] = (int)total;
-        total += pk ? q.P : (q.P + bt - 1) / bt;
+        total += pk ? (fused ? 0 : q.P) : (q.P + bt - 1) / bt;
     }
     if (total >= (1L << 31)) return hipErrorInvalidValue;
     g.start[g.n] = (int)total;                                         // (start[] is DEscending in i: see opmse_dispatch's lookup)
@@ -1079,27 +1118,71 @@ hipError_t launch_kspec_packed(PackArgs& g, hipStream_t st)
 //  * the rest: a tile of CH_BT consecutive bins of grid j (1 <= j < L), threads = (bin, row group).  It recomputes the tile's
 //    ancestor chain A_1 .. A_j from the PLANAR spectra (small matrices; lanes along the bins: coalesced) and stores A_j.
 // No workgroup waits for another one; the only cost of the independence is the re-evaluation of a few small products.
-__device__ __forceinline__ void chain_item_pipelined(const ChainArgs& g, const int t, float2* Wl)
+// mse (nullable): the tail launch's MSE description when THIS item also forms the innermost pair's post-update MSE at its bin (ChainArgs::fuse_mse:
+// the steps of the two innermost stages are marked dual) -- what opmse_packed does in a workgroup of its own otherwise
+template <bool DUAL>
+__device__ __forceinline__ void chain_item_run(const ChainArgs& g, const int t, float2* Wl, const OpMseGroup* mse)
 {
     const ChainSrc src{g};
-    chain_run_steps(src, g.Wp + (long)t * g.E, g.st_n, Wl, t, [&]() {
-        for (int i = threadIdx.x; i < CH_VMAX * OPC; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+    constexpr int VS = CH_VMAX * OPC;
+    float2* Ms = Wl + 5 * VS;                             // [OPC*OPC] the bin's moments (DUAL)
+    chain_run_steps<DUAL>(src, g.Wp + (long)t * g.E, g.st_n, Wl, t, [&]() {
+        float2 mv = make_float2(0.f, 0.f);
+        if (DUAL) {
+            const OpMsePair& q = mse->q[mse->n - 1];
+            if (threadIdx.x < OPC * OPC) mv = mse->Mhat[(long)threadIdx.x * mse->P0 + map_up(t, q.Nx, q.Ny, mse->Nx0, mse->Ny0)];
+            const int dD = q.dD;
+            for (int i = threadIdx.x; i < dD * OPC; i += 256) { const int a = i / OPC, k = i - a * OPC; Wl[2 * VS + i] = q.A[((long)k * dD + a) * q.P + t]; }
+        }
+        for (int i = threadIdx.x; i < VS; i += 256) { const int k = i / OPC, c = i - k * OPC; Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
+        if (DUAL && threadIdx.x < OPC * OPC) Ms[threadIdx.x] = mv;
     });
+    if (DUAL) {
+        // R = A - (F'(C' A / dM + b^) / dD + p^) at this bin and tr(R M^ R^H): opmse_packed's epilogue (the last stage's barrier has made region 4 visible)
+        const OpMsePair& q = mse->q[mse->n - 1];
+        const float2 *Va = Wl + 2 * VS, *Vc = Wl + 4 * VS;
+        float* redp = reinterpret_cast<float*>(Ms + OPC * OPC);
+        float part = 0.f;
+        if ((int)threadIdx.x < q.dD) {
+            const int a = threadIdx.x;
+            float2 r[OPC];
+#pragma unroll
+            for (int k = 0; k < OPC; ++k) { const float2 av = Va[a * OPC + k], fv = Vc[a * OPC + k]; r[k] = make_float2(av.x - fv.x, av.y - fv.y); }
+            part = quad_centred(r, [&](int e) { return Ms[e]; });
+            const int nyr = q.Ny / 2 + 1;
+            const int j = (int)((unsigned)t % (unsigned)nyr);
+            part *= (j > 0 && j < nyr - 1) ? 2.f : 1.f;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) redp[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = (redp[0] + redp[1]) + (redp[2] + redp[3]);
+            if (tot != 0.f) atomicAdd(q.slots + (blockIdx.x % MSE_SLOTS) * MSE_SLOT_STRIDE, tot * q.scale);
+        }
+    }
 #if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
     if (threadIdx.x == 0 && g_wgtime && blockIdx.x < WGT_MAX)
-        for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 3 * CH_VMAX * OPC + 4 + OPC * OPC)[k];
+        for (int k = 0; k < 8; ++k) g_wgtime[(size_t)5 * WGT_MAX * 2 + ((size_t)4 * WGT_MAX + blockIdx.x) * 8 + k] = reinterpret_cast<unsigned long long*>(Wl + 5 * CH_VMAX * OPC + 4 + OPC * OPC)[k];
 #endif
 }
+// (ONE instantiation per kernel: two inlined copies of the straight-line steps in one kernel spill)
 
+#if defined(AEFFT_X_WGTIME) && AEFFT_X_WGTIME
+constexpr int CH_ITEM_VECS = 5;      // (the stage stamps live behind the fifth vector)
+#else
+constexpr int CH_ITEM_VECS = 2;
+#endif
 constexpr int CH_BT = 8;
-constexpr size_t CHAIN_BIN_LDS = sizeof(float2) * 2 * CH_VMAX * OPC;
 // bx: the workgroup's index inside the chain part of the launch; Wl: dynamic LDS (per-bin items: two running vectors; planar tiles:
 // two V tiles [rows][OPC][CH_BT])
-__device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, float2* Wl)
+template <bool FUSE>
+__device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, float2* Wl, const OpMseGroup* mse = nullptr)
 {
     const int tid = threadIdx.x;
     const int L = g.L;
-    if (AEFFT_X_CHAINPIPE && (long)bx < g.Pc && g.st_n > 0) { chain_item_pipelined(g, bx, Wl); return; }      // (st_n == 0: more steps than the step table holds)
+    if (AEFFT_X_CHAINPIPE && (long)bx < g.Pc && g.st_n > 0) { chain_item_run<FUSE>(g, bx, Wl, mse); return; }      // (st_n == 0: more steps than the step table holds)
     if ((long)bx < g.Pc) {
         const int t = bx;
         const bool dc = t == 0;
@@ -1182,10 +1265,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs g)
 {
     extern __shared__ float2 Wl[];
-    chain_body(g, blockIdx.x, Wl);
+    chain_body<false>(g, blockIdx.x, Wl);
 }
 
-static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
+// fuse (in/out, nullable): the caller would like the per-bin items to form the innermost pair's post-update MSE as well (chain_item_run<true>); granted
+// when the items run pipelined and the record offsets of that pair's C and F are the ones the MSE description names (offC, offF): then the steps of
+// those two stages carry the dual mark (bit 30 of the offset word)
+static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out, bool* fuse = nullptr, unsigned offC = 0, unsigned offF = 0)
 {
     if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
     for (int l = 0; l < g.L; ++l) {
@@ -1195,15 +1281,23 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     {
         // the per-bin item's step list (chain_item_pipelined): stage si = level si's encoder matrix, then the decoders from the innermost level out
         int n = 0; unsigned off = 0;
-        bool fits = true;
+        bool fits = true, offs_ok = true;
+        int dual_lo = 0, dual_hi = 0;                                   // steps [dual_lo, dual_hi): the innermost pair's two stages
         for (int si = 0; si < 2 * g.L && fits; ++si) {
             const bool enc = si < g.L;
             const int l = enc ? si : 2 * g.L - 1 - si;
             const int R = enc ? g.lv[l].dM : g.lv[l].dD, K = enc ? g.lv[l].dD : g.lv[l].dM;
+            if (si == g.L - 1) { dual_lo = n; offs_ok = offs_ok && off == offC; }
+            if (si == g.L) offs_ok = offs_ok && off == offF;
             fits = chain_add_stage(g.st_off, g.st_desc, &n, CH_MAXSTEPS, R, K, off, si & 1, enc, l);
+            if (si == g.L) dual_hi = n;
             off += (unsigned)((R * K + 1) & ~1);
         }
         g.st_n = fits ? n : 0;                                          // (0: the item runs stage by stage, chain_stage_rec)
+        if (fuse) {
+            *fuse = *fuse && fits && offs_ok && AEFFT_X_CHAINPIPE;
+            if (*fuse) for (int i = dual_lo; i < dual_hi; ++i) g.st_off[i] |= 1u << 30;
+        }
         if ((double)OPC * CH_VMAX * (double)g.Pc * sizeof(float2) >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit byte offsets of the output stores, st8)
     }
     long total = g.Pc;
@@ -1214,7 +1308,8 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out)
     for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
     g.vt_elems = rmax * OPC * CH_BT;
     *nblocks = total;
-    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, CHAIN_BIN_LDS + sizeof(float2) * CH_VMAX * OPC + 256 /* (experiment builds: stage stamps behind a third vector) */);
+    // per-bin items: two running vectors, and with the fused MSE three more (A, C'A, F'C'A of the ending step), the bin's moments and the wave sums
+    *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, sizeof(float2) * ((fuse && *fuse ? 5 : CH_ITEM_VECS) * (size_t)CH_VMAX * OPC + OPC * OPC + 4) + 256 /* (experiment builds: stage stamps) */);
     return hipSuccess;
 }
 
@@ -1240,12 +1335,16 @@ hipError_t launch_chain(ChainArgs& g, hipStream_t st, hipEvent_t done)
 #ifndef AEFFT_X_TAIL_W
 #define AEFFT_X_TAIL_W 6
 #endif
-template <bool LEAN>
-__global__ __launch_bounds__(256, LEAN ? AEFFT_X_TAIL_W : 4) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
+// (with the fused MSE the items carry a second set of sums: 5 waves per SIMD, 96 registers -- at 6 the back end spills 20 bytes; cfg5 82.6-84 vs 82 us)
+#ifndef AEFFT_X_TAIL_WF
+#define AEFFT_X_TAIL_WF 5
+#endif
+template <bool LEAN, bool FUSE>
+__global__ __launch_bounds__(256, LEAN ? (FUSE ? AEFFT_X_TAIL_WF : AEFFT_X_TAIL_W) : 4) void tail_kernel(const OpMseGroup g, const ChainArgs ch, const UpdateGroup ug, const int nchain, const int nupd_start)
 {
     AEFFT_WGTIME(4);
     extern __shared__ float2 sh[];
-    if ((int)blockIdx.x < nchain) { chain_body(ch, blockIdx.x, sh); return; }
+    if ((int)blockIdx.x < nchain) { chain_body<FUSE>(ch, blockIdx.x, sh, &g); return; }
     if ((int)blockIdx.x >= nupd_start) {
         const int blk = blockIdx.x - nupd_start;
         int p = 0;
@@ -1264,8 +1363,25 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st, ChainArgs* chain, c
 {
     long nchain = 0, nmse = 0;
     size_t lds_c = 0, lds_m = 0;
-    if (chain) { const hipError_t e = chain_geometry(*chain, &nchain, &lds_c); if (e != hipSuccess) return e; }
-    { const hipError_t e = opmse_geometry(g, (int)nchain, &nmse, &lds_m); if (e != hipSuccess) return e; }
+#ifndef AEFFT_X_FUSEMSE
+#define AEFFT_X_FUSEMSE 1
+#endif
+    // the innermost pair's MSE inside the chain's per-bin items: both read that pair's C', F' from the same record at the same bin
+    bool fuse = AEFFT_X_FUSEMSE && chain && g.Wp && chain->Wp == g.Wp && chain->E == g.E && chain->Pc == g.q[g.n - 1].P &&
+                g.q[g.n - 1].dD <= CH_VMAX && g.q[g.n - 1].dM <= CH_VMAX && g.q[g.n - 1].dD <= 256;
+    if (chain) { const hipError_t e = chain_geometry(*chain, &nchain, &lds_c, &fuse, (unsigned)g.offC, (unsigned)g.offF); if (e != hipSuccess) return e; }
+    { const hipError_t e = opmse_geometry(g, (int)nchain, &nmse, &lds_m, false); if (e != hipSuccess) return e; }
+    // ... where the launch is bound by its resident slots (cfg5: 11 000 workgroups, tail 89 -> 82 us).  Where the items themselves are the launch's
+    // long pole (cfg3-P2: 3 634 workgroups) the two wider stages lengthen it: 23.9 -> 26.1 us.
+    if (fuse && nchain + nmse < 4 * 1536 && !flag(AEFFT_F_CHAINMSE)) {
+        fuse = false;
+        for (int i = 0; i < chain->st_n; ++i) chain->st_off[i] &= ~(1u << 30);
+        const hipError_t e = chain_geometry(*chain, &nchain, &lds_c); if (e != hipSuccess) return e;      // (the items' LDS without the MSE's vectors)
+    }
+    if (fuse) {
+        const hipError_t e = opmse_geometry(g, (int)nchain, &nmse, &lds_m, true); if (e != hipSuccess) return e;
+        if (!g.Wp) return hipErrorInvalidValue;                          // (cannot happen: the same conditions keep the pair packed)
+    }
     int nupd = 0;
     UpdateGroup ug = g_tail_ug_none;
     if (weights_upd && weights_upd->n > 0) {
@@ -1279,16 +1395,19 @@ hipError_t launch_opmse_group(OpMseGroup& g, hipStream_t st, ChainArgs* chain, c
 #endif
     bool lean = AEFFT_X_LEANTAIL != 0;
     for (int i = 0; i < g.n && lean; ++i) lean = g.q[i].G != nullptr || (i == g.n - 1 && g.Wp != nullptr);      // (after opmse_geometry: Wp is null unless the innermost pair goes packed)
-    if (lds > 64 * 1024) {
-        const hipError_t e = lean ? hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     const long total = nchain + nmse + nupd;
     if (total >= (1L << 31)) return hipErrorInvalidValue;
-    if (lean) tail_kernel<true><<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
-    else tail_kernel<false><<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
-    return hipGetLastError();
+    auto go = [&](auto LEANT, auto FUSET) -> hipError_t {
+        constexpr bool LN = decltype(LEANT)::value, FS = decltype(FUSET)::value;
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<LN, FS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        tail_kernel<LN, FS><<<dim3((unsigned)total), 256, lds, st>>>(g, chain ? *chain : g_tail_chain_none, ug, (int)nchain, (int)(nchain + nmse));
+        return hipGetLastError();
+    };
+    if (lean) return fuse ? go(std::true_type{}, std::true_type{}) : go(std::true_type{}, std::false_type{});
+    return fuse ? go(std::false_type{}, std::true_type{}) : go(std::false_type{}, std::false_type{});
 }
 
 }  // namespace aefft

@@ -86,7 +86,9 @@ enum {
     AEFFT_F_NOAHEAD = 1 << 19,    /* operator form: the next step's operator chain as the first launch of that step instead of riding in this step's last launch */
     AEFFT_F_NORCORR = 1 << 20,    /* spatial mode: dC through the back-convolved error (a dM-plane tensor) instead of the error-input correlation R */
     AEFFT_F_NOLAZYMSE = 1 << 21,   /* aefft_net_step_apply(mse_d = NULL) still sums the MSE slots in a launch of its own instead of leaving them to the next step's gradient launch */
-    AEFFT_F_SMALLOVERLAP = 1 << 22 /* reconstructions below 8 MB take the side stream as well (the test suite's small nets then run the two-stream path of the large ones) */
+    AEFFT_F_SMALLOVERLAP = 1 << 22, /* reconstructions below 8 MB take the side stream as well (the test suite's small nets then run the two-stream path of the large ones) */
+    AEFFT_F_CHAINMSE = 1 << 23     /* operator form with the chain: the innermost pair's post-update MSE inside the chain's per-bin items whatever the launch's size
+                                   * (by default only in launches of more than ~6 000 workgroups, which are bound by their resident slots) */
 };
 int aefft_ctx_set_flags(aefft_ctx* ctx, unsigned flags);
 unsigned aefft_ctx_get_flags(const aefft_ctx* ctx);

@@ -228,7 +228,7 @@ def test_golden_forward_and_bursts(ctx, tag, D, N, maps, Nk, s):
 # Every alternative code path of the training step must give the oracle's numbers (development switches, aefft_ctx_set_flags).
 STEP_PATHS = ["", "NOOPFORM", "NOOPFORM,GTAPS", "NOOPFORM,NOQPATH", "NOOPFORM,NOCOMPACT", "NOOPFORM,NOLAZY", "NOOPFORM,NOGROUP", "NOOPFORM,NOFUSEMSE",
               "NOOPFORM,NOMFMA", "NOOPFORM,NOOVERLAP", "NOOPFORM,NOFUSECROP", "NOMFMA", "NOGROUP", "NOCHAIN", "NOCOMPACT", "NOLAZY", "NOOVERLAP",
-              "NOFUSEUPD", "NOAHEAD", "NOCHAIN,NOFUSEUPD,GTAPS"]
+              "NOFUSEUPD", "NOAHEAD", "NOCHAIN,NOFUSEUPD,GTAPS", "CHAINMSE"]
 
 
 @pytest.mark.parametrize("path", STEP_PATHS)

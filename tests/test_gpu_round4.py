@@ -24,7 +24,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("path", ["", "NOOPFORM"])
+@pytest.mark.parametrize("path", ["", "NOOPFORM", "CHAINMSE"])
 def test_config5_full_map_counts_vs_oracle_every_pair(ctx, flags, path):
     """BASELINE configs[4]'s network -- 5 pairs 3->8->16->32->64->128 maps, 5x5, pool 2, symmetric weights + multiobjective -- at its
     FULL map counts on 256x256 planes (the oracle's cost is in the maps, not the planes): one training step against
@@ -44,7 +44,7 @@ def test_config5_full_map_counts_vs_oracle_every_pair(ctx, flags, path):
     net = aefft.Net(ctx, D, N, N, maps, Nk, s, batch=B)
     for l, w in enumerate(ws):
         net.set_pair(l, *w)
-    assert net.step_form() == ("per_frame" if path else "operator_chain")
+    assert net.step_form() == ("per_frame" if "NOOPFORM" in path else "operator_chain")
     recon, mse = ctx.empty(B, D, N, N), ctx.empty(L)
     net.step_grad(ctx.dev(xs), recon)
     gbuf = host(net.grad_buffer()).copy()
@@ -116,7 +116,7 @@ def test_default_rate_trajectory_300_steps_vs_float64_oracle(ctx, flags, path):
     net = aefft.Net(ctx, g["D"], g["N"], g["N"], g["maps"], g["Nk"], g["s"], batch=g["B"])
     for l, w in enumerate(ws):
         net.set_pair(l, *w)
-    assert net.step_form() == ("per_frame" if path else "operator_chain")
+    assert net.step_form() == ("per_frame" if "NOOPFORM" in path else "operator_chain")
     x = ctx.dev(xs)
     recon = ctx.empty(*xs.shape)
     mse = ctx.empty(g["steps"], L)
