@@ -493,15 +493,15 @@ def main():
         M4, M3, M5 = [8, 16, 32, 64], [8, 16, 32], [8, 16, 32, 64, 128]
         variants = {
             "per_frame_form": fft_variant(aefft, torch, np, ctx, "cfg3-P2, per-frame form (NOOPFORM: every layer for every frame, round 1's step)",
-                                          512, M4, 2, 32, steps=20, warmup=5, flags=("NOOPFORM",)),
+                                          512, M4, 2, 32, steps=100, warmup=20, flags=("NOOPFORM",)),
             "u8_frames": fft_variant(aefft, torch, np, ctx, "cfg3-P2 with the frames resident as 8-bit pixels (aefft_net_step_grad_u8: what a camera delivers; the headline "
                                      "keeps the reference's float frames); same pixel values, same results", 512, M4, 2, 32, steps=200, warmup=20, u8=True),
             "p1": fft_variant(aefft, torch, np, ctx, "cfg3-P1: as the headline but pool 1/layer (all pairs at 512x512; 5.7 GB of kernel spectra)",
-                              512, M4, 1, 32, steps=10, warmup=2),
+                              512, M4, 1, 32, steps=30, warmup=5),
             "cfg2": fft_variant(aefft, torch, np, ctx, "cfg2: 256x256x3, 3 pairs 3->8->16->32, 5x5, pool 2/layer, B = 1 (BASELINE configs[1])",
-                                256, M3, 2, 1, steps=50, warmup=5),
+                                256, M3, 2, 1, steps=500, warmup=50),
             "cfg5": fft_variant(aefft, torch, np, ctx, "cfg5 per-GPU shape: 1024x1024x3, 5 pairs 3->8->...->128, 5x5, pool 2/layer, tied weights + "
-                                "multiobjective (sym=1, maxdiff=1), 32 frames (BASELINE configs[4])", 1024, M5, 2, 32, steps=10, warmup=2, sym=1, maxdiff=1),
+                                "multiobjective (sym=1, maxdiff=1), 32 frames (BASELINE configs[4])", 1024, M5, 2, 32, steps=60, warmup=10, sym=1, maxdiff=1),
             "spatial": variant_spatial(aefft, torch, np, ctx)}
 
     # (the CPU baseline last: its 16 worker processes leave the host's CPU share throttled for a moment, which the launch-bound variants would see)
