@@ -253,6 +253,7 @@ def test_step_equals_oracle_batch_iteration(ctx, B, path, flags):
     (2, 128, 128, [8, 16], 5, 2, 1),       # ... dD = 2; pair 0 on 64x64: the inverse transform of S in two row chunks
     (3, 128, 128, [4, 6], 3, 2, 2),        # 3x3 kernels (5x5 offsets) with row chunks: the chunk sum of the 3x3 weight-gradient kernel
     (3, 64, 64, [32, 40, 8], 5, 2, 2),     # a middle pair with dD = 32: rows of G' beyond the 16 requested up front (opmse_gbody), G' tiles of 2 planes
+    (3, 64, 64, [128, 128, 128], 5, 2, 2), # 67 steps per chain item: more than the step table holds -- the items run stage by stage (chain_stage_rec)
     (3, 1024, 1024, [4], 5, 2, 2),         # 2056 workgroups in the moments launch: the 4-frame-batch instantiation msgrad_kernel<4> (several rounds of slots)
 ])
 def test_step_shapes_vs_oracle(ctx, D, Nx, Ny, maps, Nk, s, B):
