@@ -209,7 +209,10 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
     float2 cp[NL / 2 > 0 ? NL / 2 : 1];
     kspec_col_phases<NL>(tw, j, Ny, NyB, cp);
-    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, map_up_row(i0 + t / H, Nx, NxB), t % H + 1, NxB);
+    const bool one_trip = nrows * H <= (int)blockDim.x;          // (the row phases: requested here, stored behind the taps' loads -- one round trip for both)
+    float2 rp0 = make_float2(0.f, 0.f);
+    if (one_trip) { if ((int)threadIdx.x < nrows * H) rp0 = phase_tw(tw, map_up_row(i0 + threadIdx.x / H, Nx, NxB), threadIdx.x % H + 1, NxB); }
+    else for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, map_up_row(i0 + t / H, Nx, NxB), t % H + 1, NxB);
     {
         // (through the pending update when there is one -- uniform --: w - clip_step(g, D), TapUpd)
         const long e0 = (long)bx * ppb * (NK * NL);
@@ -230,6 +233,7 @@ __device__ __forceinline__ void kspec_body(const float* __restrict__ kern, float
             }
         }
     }
+    if (one_trip && (int)threadIdx.x < nrows * H) rowph[threadIdx.x] = rp0;
     __syncthreads();
     AEFFT_WGSTAMP(3, 0);
     const long plane = (long)bx * ppb + pl;
@@ -252,11 +256,17 @@ __device__ __forceinline__ void gspec_gbody(const GtapSrc& gs, float2* __restric
     const int pl = threadIdx.x / Nyr, j = threadIdx.x - pl * Nyr;
     float2 cp[H];
     kspec_col_phases<T>(tw, j, Ny, Ny, cp);
-    for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, i0 + t / H, t % H + 1, Nx);
+    // the row phases: requested here, stored BEHIND the tap stage's loads (a load -> LDS store in front of them is a round trip of its own:
+    // the first barrier of these workgroups came at 5.8-7 us against 3.8 for the plain transform's)
+    const bool one_trip = nrows * H <= (int)blockDim.x;
+    float2 rp0 = make_float2(0.f, 0.f);
+    if (one_trip) { if ((int)threadIdx.x < nrows * H) rp0 = phase_tw(tw, i0 + threadIdx.x / H, threadIdx.x % H + 1, Nx); }
+    else for (int t = threadIdx.x; t < nrows * H; t += blockDim.x) rowph[t] = phase_tw(tw, i0 + t / H, t % H + 1, Nx);
     const int tiles = (gs.dD + ppb - 1) / ppb;
     const int dp = bx / tiles, d0 = (bx - dp * tiles) * ppb;
     const int np = min(ppb, gs.dD - d0);
     gtaps_stage<NK, MU>(gs, upd, dp, d0, np, taps_s, work);
+    if (one_trip && (int)threadIdx.x < nrows * H) rowph[threadIdx.x] = rp0;
     __syncthreads();
     AEFFT_WGSTAMP(3, 3);
     if (pl >= np) return;
