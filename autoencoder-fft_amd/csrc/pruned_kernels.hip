@@ -784,6 +784,14 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
         g.start[p] = total; total += g.pblocks[p] * chunks;
     }
     g.start[g.n] = total;
+    {
+        // HBM-sized write streams (cfg3-P1: 5.7 GB of planar spectra, 1.4 GB of G' planes) want FEW resident workgroups: every one of them is a
+        // write stream of its own rows, and the fewer streams the memory controllers see the better they keep their pages -- 2 per CU (a dynamic LDS
+        // size of 60 KB asks for that) 5.55 TB/s, 3-4 per CU 5.3, 6 per CU (the 9x9-tap launch at 62 registers) 4.3: 1 375 -> 1 285 us for the two launches
+        double wbytes = 0;
+        for (int p = 0; p < g.n; ++p) wbytes += (double)g.q[p].planes * g.q[p].Nx * (g.q[p].Ny / 2 + 1) * 8.0;
+        if (wbytes > 512e6) lds = std::max(lds, (size_t)60000);
+    }
     bool has_g = false;                                   // (which instantiation: see gtaps_stage)
     for (int p = 0; p < g.n; ++p) has_g = has_g || g.gsrc[p].f != nullptr;
     if (lds > 64 * 1024) {
