@@ -812,13 +812,13 @@ template <int NK, int NL> static hipError_t run_kspec_group(PrunedGroup& g, cons
 // geometry of one problem of the grouped inverse transform
 struct KgGeom { int ppb, S, RB, chunks, pblocks; };
 static constexpr int KG_NT = 512, KG_MAXCHUNKS = 32;     // (8 row chunks unless the problem would then leave most of the chip idle: see kgrad_group_geom)
-static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
+static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks, int nt = KG_NT)
 {
     KgGeom o{};
     const int Nyr = Ny / 2 + 1;
-    o.ppb = std::max(1, std::min(256, KG_NT) / Nyr);      // ~256 columns per workgroup, the remaining threads become row slices
+    o.ppb = std::max(1, std::min(256, nt) / Nyr);         // ~256 columns per workgroup, the remaining threads become row slices
     if (o.ppb > planes) o.ppb = (int)planes;
-    o.S = std::max(1, KG_NT / (o.ppb * Nyr));
+    o.S = std::max(1, nt / (o.ppb * Nyr));
     while (o.S > 1 && Nx / o.S < 8) --o.S;
     o.RB = (Nx + o.S - 1) / o.S;
     o.chunks = 1;
@@ -840,23 +840,25 @@ static KgGeom kgrad_group_geom(long planes, int Nx, int Ny, int max_chunks)
 // row chunks the grouped inverse transform would like for this problem: size the destination [planes][chunks][taps]
 int kgrad_group_chunks(long planes, int Nx, int Ny) { return kgrad_group_geom(planes, Nx, Ny, KG_MAXCHUNKS).chunks; }
 
-template <int NK, int NL> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st, BiasGradGroup* bgp = nullptr)
+// (NT = 576 for grids of 257 columns -- cfg3-P1: one thread per column leaves 255 of 512 threads without a column, two row slices of 257 columns fill 514
+// of 576 -- measured 509 vs 375 us there: no.)
+template <int NK, int NL, int NT> static hipError_t run_kgrad_group(PrunedGroup& g, const float2* tw, hipStream_t st, BiasGradGroup* bgp = nullptr)
 {
-    constexpr int NT = KG_NT;
     int total = 0; size_t lds = 0;
     // more than 8 row chunks only where a problem's 64-row workgroups would be the stragglers of a SMALL launch (cfg5's outermost pair);
     // in a launch of thousands of equally long workgroups (cfg3-P1: every pair on the 512^2 grid) they only add partial sums: 411 -> 456 us
     long total8 = 0;
-    for (int p = 0; p < g.n; ++p) { const KgGeom k8 = kgrad_group_geom(g.q[p].planes, g.q[p].Nx, g.q[p].Ny, std::min(8, std::max(1, g.chunks[p]))); total8 += (long)k8.pblocks * k8.chunks; }
+    for (int p = 0; p < g.n; ++p) { const KgGeom k8 = kgrad_group_geom(g.q[p].planes, g.q[p].Nx, g.q[p].Ny, std::min(8, std::max(1, g.chunks[p])), NT); total8 += (long)k8.pblocks * k8.chunks; }
     const int launch_cap = total8 < 2048 ? KG_MAXCHUNKS : 8;
     for (int p = 0; p < g.n; ++p) {
         const PrunedProb& q = g.q[p];
         const int Nyr = q.Ny / 2 + 1;
         if (Nyr > NT) return hipErrorInvalidValue;
-        const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::min(launch_cap, std::max(1, g.chunks[p])));     // in: room at dst; out: chunks used
+        const KgGeom k = kgrad_group_geom(q.planes, q.Nx, q.Ny, std::min(launch_cap, std::max(1, g.chunks[p])), NT);     // in: room at dst; out: chunks used
         g.ppb[p] = k.ppb; g.rows[p] = k.S; g.rb[p] = k.RB; g.chunks[p] = k.chunks; g.pblocks[p] = k.pblocks;
         g.start[p] = total; total += k.pblocks * k.chunks;
-        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)(NL / 2 + 1) * std::max(NT, k.ppb * NK)));      // (part: [tasks x column slices <= max(NT, tasks)][NL/2+1][2])
+        const int ntask = k.ppb * NK, js = std::min(16, std::max(1, NT / ntask));      // (the column stage's tasks and column slices, as kgrad_sliced_body forms them)
+        lds = std::max(lds, sizeof(float2) * ((size_t)k.S * k.RB * NK + (size_t)Nyr * NL) + sizeof(float) * (2 * NK * (NT + 1) + 2 * (size_t)(NL / 2 + 1) * ntask * js));      // (part: [tasks x column slices][NL/2+1][2])
     }
     g.start[g.n] = total;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -902,8 +904,8 @@ static bool taps_group_ok(const PrunedGroup& g, const float2* tw)
 hipError_t launch_kgrad_group_taps(PrunedGroup& g, const float2* tw, int T, hipStream_t st, BiasGradGroup* bias)
 {
     if (!taps_group_ok(g, tw) || (bias && (bias->n < 1 || bias->n > 8))) return hipErrorInvalidValue;
-    if (T == 5) return run_kgrad_group<5, 5>(g, tw, st, bias);
-    if (T == 9) return run_kgrad_group<9, 9>(g, tw, st, bias);
+    if (T == 5) return run_kgrad_group<5, 5, KG_NT>(g, tw, st, bias);
+    if (T == 9) return run_kgrad_group<9, 9, KG_NT>(g, tw, st, bias);
     return hipErrorInvalidValue;
 }
 
@@ -928,9 +930,9 @@ hipError_t launch_kspec_group_taps(PrunedGroup& g, const float2* tw, int T, hipS
 hipError_t launch_kgrad_group(PrunedGroup& g, const float2* tw, int Nk, int Nl, hipStream_t st)
 {
     if (!pruned_group_ok(g, tw, Nk, Nl)) return hipErrorInvalidValue;
-    if (Nk == 3) return run_kgrad_group<3, 3>(g, tw, st);
-    if (Nk == 5) return run_kgrad_group<5, 5>(g, tw, st);
-    return run_kgrad_group<7, 7>(g, tw, st);
+    if (Nk == 3) return run_kgrad_group<3, 3, KG_NT>(g, tw, st);
+    if (Nk == 5) return run_kgrad_group<5, 5, KG_NT>(g, tw, st);
+    return run_kgrad_group<7, 7, KG_NT>(g, tw, st);
 }
 
 hipError_t launch_kspec(const float* k, float2* K, const float2* tw, long planes, int Nx, int Ny, int Nk, int Nl, hipStream_t st)
