@@ -223,6 +223,7 @@ struct ChainArgs {
     const float2* Wp; int E;   // bin-major copy of every matrix a coarsest-grid bin needs (kspec_packed_kernel)
     int tile_start[9];         // (filled by launch_chain) first workgroup of the planar tiles of grid j
     int vt_elems;              // (filled by launch_chain) elements of one V tile of the planar part
+    int tile_bt[8];            // (filled by launch_chain) bins per planar tile of grid j (8, 16 or 32)
     // (filled by launch_chain) the per-bin item's step list (chain_item_pipelined, opform_kernels.hip)
     unsigned st_off[CH_MAXSTEPS], st_desc[CH_MAXSTEPS]; int st_n;
 };

@@ -1205,15 +1205,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
     int j = 1;
 #pragma unroll
     for (int i = 2; i < 8; ++i) if (i < L && bx >= g.tile_start[i]) j = i;
-    const int bl = tid % CH_BT, ry = tid / CH_BT;
-    constexpr int RT = 256 / CH_BT;
+    // bins per tile: 256 / (rows of the tile's last stage), 8 .. 32 -- every thread owns a (bin, row) of that stage (8 bins for every level left three
+    // quarters of the threads of a grid-1 tile without a row: 1 372 tile workgroups at cfg3, 460 now), and a tile's plane reads are 64 .. 256-byte pieces
+    const int bt = g.tile_bt[j], RT = 256 / bt;
+    const int bl = tid & (bt - 1), ry = tid / bt;
     const ChainLevel lj = g.lv[j];
-    const long s0 = (long)(bx - g.tile_start[j]) * CH_BT;
+    const long s0 = (long)(bx - g.tile_start[j]) * bt;
     const long s = min(s0 + bl, lj.P - 1);
     const bool ok = s0 + bl < lj.P;
     // V tiles in LDS: [row][col][bin], ping-pong halves of Wl
     // (addressed as offsets off ONE LDS base: a select between two pointers compiles to flat loads, which wait for every counter)
-    for (int i = tid; i < OPC * OPC * CH_BT; i += 256) { const int b2 = i % CH_BT, c = (i / CH_BT) % OPC, k = i / (CH_BT * OPC); Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); (void)b2; }
+    for (int i = tid; i < OPC * OPC * bt; i += 256) { const int c = (i / bt) % OPC, k = i / (bt * OPC); Wl[i] = make_float2((k == c && c < OPC - 1) ? 1.f : 0.f, 0.f); }
     // (a ROLLED loop over the levels: unrolled, the seven copies of the stage body cost 121 registers -- half the occupancy of the
     // launch, which hosts the per-bin items and the MSE as well; the level's descriptor is a uniform, scalar-loaded index)
 #pragma unroll 1
@@ -1242,7 +1244,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int c = 0; c < OPC; ++c) cfma2(acc[c], wv[u], Vin[((k0 + u) * OPC + c) * CH_BT + bl]);
+                    for (int c = 0; c < OPC; ++c) cfma2(acc[c], wv[u], Vin[((k0 + u) * OPC + c) * bt + bl]);
             };
             int k0 = 0;
             for (; k0 + 16 <= K; k0 += 16) grp(k0, std::integral_constant<int, 16>{});
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& g, const int bx, flo
             if (sbi == 0) acc[OPC - 1].x += w.b[r] * NN;
 #pragma unroll
             for (int c = 0; c < OPC; ++c) {
-                Vout[(r * OPC + c) * CH_BT + bl] = acc[c];
+                Vout[(r * OPC + c) * bt + bl] = acc[c];
                 if (i == j && ok) lj.A[((long)c * R + r) * lj.P + s] = acc[c];
             }
         }
@@ -1276,7 +1278,7 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out, b
     if (g.L < 1 || g.L > 8 || !g.Wp || g.Pc < 1) return hipErrorInvalidValue;
     for (int l = 0; l < g.L; ++l) {
         if (g.lv[l].dD > CH_VMAX || g.lv[l].dM > CH_VMAX) return hipErrorInvalidValue;
-        if (l + 1 < g.L && (size_t)2 * g.lv[l].dM * OPC * CH_BT > CH_WL) return hipErrorInvalidValue;     // planar tiles: two V tiles share the LDS buffer
+        if (l + 1 < g.L && (size_t)2 * g.lv[l].dM * OPC * CH_BT > CH_WL) return hipErrorInvalidValue;     // planar tiles: two V tiles share the LDS buffer (at the narrowest tile)
     }
     {
         // the per-bin item's step list (chain_item_pipelined): stage si = level si's encoder matrix, then the decoders from the innermost level out
@@ -1301,12 +1303,19 @@ static hipError_t chain_geometry(ChainArgs& g, long* nblocks, size_t* lds_out, b
         if ((double)OPC * CH_VMAX * (double)g.Pc * sizeof(float2) >= 4294967296.0) return hipErrorInvalidValue;      // (32-bit byte offsets of the output stores, st8)
     }
     long total = g.Pc;
-    for (int j = 1; j < g.L; ++j) { g.tile_start[j] = (int)total; total += (g.lv[j].P + CH_BT - 1) / CH_BT; }
+    int vt = OPC * OPC * 32;                                            // (the identity start vector of the widest tile)
+    for (int j = 1; j < g.L; ++j) {
+        int rj = OPC;                                                   // most rows of a stage of a grid-j tile (levels 0 .. j-1)
+        for (int l = 0; l < j; ++l) rj = std::max(rj, g.lv[l].dM);
+        int bt = 32;
+        while (bt > CH_BT && bt * rj > 256) bt >>= 1;
+        g.tile_bt[j] = bt;
+        vt = std::max(vt, rj * OPC * bt);
+        g.tile_start[j] = (int)total; total += (g.lv[j].P + bt - 1) / bt;
+    }
     g.tile_start[g.L] = (int)total;
     if (total >= (1L << 31)) return hipErrorInvalidValue;
-    int rmax = OPC;
-    for (int l = 0; l + 1 < g.L; ++l) rmax = std::max(rmax, g.lv[l].dM);
-    g.vt_elems = rmax * OPC * CH_BT;
+    g.vt_elems = vt;
     *nblocks = total;
     // per-bin items: two running vectors, and with the fused MSE three more (A, C'A, F'C'A of the ending step), the bin's moments and the wave sums
     *lds_out = std::max(sizeof(float2) * 2 * g.vt_elems, sizeof(float2) * ((fuse && *fuse ? 5 : CH_ITEM_VECS) * (size_t)CH_VMAX * OPC + OPC * OPC + 4) + 256 /* (experiment builds: stage stamps) */);
